@@ -1,0 +1,161 @@
+/*
+ * csim.h -- C-ABI of the MI355X batched MNA solve engine (libcsim.so).
+ *
+ * extern "C", plain pointers and sizes, no C++/torch types, no exceptions
+ * across the boundary: every call returns 0 (CSIM_OK) or a negative error and
+ * csim_last_error() describes it.  Per-instance trouble (non-convergence,
+ * non-finite solve, tiny pivot) never fails a call: it is reported in the
+ * per-instance status words (CSIM_ST_* in csim_ir.h), so one bad instance
+ * cannot kill a batch -- this replaces the reference's stderr WARNINGs and
+ * its std::runtime_error (src/tanalisis.cpp:360-376, src/dcanalysis.cpp:135-158).
+ *
+ * There is NO CPU backend behind this ABI.  csim_engine_create() fails with
+ * CSIM_ERR_NO_DEVICE when no HIP device is usable; nothing falls back to host
+ * arithmetic.  (The CPU restatement lives in oracle/ and is test-only.)
+ *
+ * Reference interface each group replaces (ZyuRao/CircuitSimulator):
+ *   csim_netlist_*        parseNetlist()                 include/parser.hpp:67-75
+ *                         Circuit::assignEquationIndices src/circuit.cpp:42-61  (src/main.cpp:29,34)
+ *   csim_dc_batch*        computeDcOperatingPoint()      include/tanalisis.hpp:9
+ *                         dcSolve/dcSolveLU              include/dcanalysis.hpp:8-14, src/dcanalysis.cpp:242-262
+ *   csim_tran_batch*      runTransientAnalysisBackwardEuler  include/tanalisis.hpp:15-17, src/tanalisis.cpp:83-424
+ *   csim_lu_solve_batch   Solver::solveLinearSystemLU / luDecompose  include/solver.hpp:30-131
+ *   (stamping)            Element::stamp virtuals        include/element.hpp:28-31, src/element.cpp:9-307
+ *                         -- no entry point of their own: the stamps run inside the DC/TRAN kernels.
+ *
+ * Data layout.  Every per-instance table is "slot-major": element [i][b] at
+ * i*B + b, b = instance.  That is the coalesced layout for the
+ * lane-per-instance kernels and costs the wave-per-instance kernels one
+ * strided read per launch.  The *_dev entry points take DEVICE pointers in
+ * that layout and enqueue on the given HIP stream without synchronising; the
+ * host-pointer entry points take the instance-major tables proposed in
+ * SURVEY.md 8(b) ([B][P], [B][N]) and do the copies and transposes.
+ */
+#ifndef CSIM_H
+#define CSIM_H
+
+#include <stdint.h>
+#include "csim_ir.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSIM_OK                0
+#define CSIM_ERR_ARG          -1   /* null pointer, bad size                       */
+#define CSIM_ERR_IO           -2   /* netlist file cannot be opened                */
+#define CSIM_ERR_NO_DEVICE    -3   /* no usable HIP device: there is no CPU path   */
+#define CSIM_ERR_HIP          -4   /* a HIP runtime call failed                    */
+#define CSIM_ERR_UNSUPPORTED  -5   /* circuit outside what the kernels cover       */
+#define CSIM_ERR_EMPTY        -6   /* circuit has no unknowns                      */
+#define CSIM_ERR_CONFIG       -7   /* invalid .TRAN numbers (tstep/tstop <= 0)     */
+
+typedef struct csim_netlist csim_netlist;
+typedef struct csim_engine  csim_engine;
+
+const char* csim_last_error(void);
+const char* csim_version(void);
+
+/* ---------------------------------------------------------------- netlist
+ * Parse + index a netlist (host only, runs once, microseconds).             */
+int  csim_netlist_parse_file(const char* path, csim_netlist** out);
+/* same, from memory (what a rank receives from the broadcast of the netlist) */
+int  csim_netlist_parse_text(const char* text, int64_t len, csim_netlist** out);
+void csim_netlist_free(csim_netlist* nl);
+
+/* flattened circuit; owned by the netlist, valid until csim_netlist_free */
+const csim_ir* csim_netlist_ir(const csim_netlist* nl);
+/* "Circuit summary" numbers of src/main.cpp:36-41 */
+int  csim_netlist_counts(const csim_netlist* nl, int32_t* n_nodes, int32_t* n_elems,
+                         int32_t* n_unknowns, int32_t* n_node_eq, int32_t* n_branch_eq);
+/* nominal parameter vector, P doubles */
+int  csim_netlist_nominal_params(const csim_netlist* nl, double* out);
+/* node name (node equations) or element name (branch equations) of equation eq */
+const char* csim_netlist_eq_name(const csim_netlist* nl, int32_t eq);
+/* equation index of a node name, -1 for ground, -2 if unknown */
+int  csim_netlist_node_eq(const csim_netlist* nl, const char* node_name);
+/* .TRAN card (src/parser.cpp:497-524) */
+int  csim_netlist_tran(const csim_netlist* nl, int32_t* enabled, double* tstep, double* tstop, double* tstart);
+/* node-voltage probes named by .PLOTNV / .PRINT cards, as equation indices */
+int  csim_netlist_num_probes(const csim_netlist* nl);
+int  csim_netlist_probe_eq(const csim_netlist* nl, int32_t i);
+/* .DC cards (src/parser.cpp:476-495): source element index and sweep numbers */
+int  csim_netlist_num_dc_sweeps(const csim_netlist* nl);
+int  csim_netlist_dc_sweep(const csim_netlist* nl, int32_t i, int32_t* src_elem,
+                           double* start, double* stop, double* step);
+/* header line of the reference's transient CSV (src/tanalisis.cpp:191-206):
+ * "time,V(<node>)...,I(<elem>)..."; returns the length needed (excl. NUL) */
+int  csim_netlist_csv_header(const csim_netlist* nl, char* buf, int32_t cap);
+/* Monte-Carlo recipe per parameter slot: 0 fixed, 1 scaled by (1+sigma z),
+ * 2 MOS K rebuilt from a MU draw: K = (MU(1+sigma z))*COX*(W/L)              */
+int  csim_netlist_mc_kinds(const csim_netlist* nl, int32_t* kinds);
+
+/* ----------------------------------------------------------------- engine */
+/* One engine per (circuit, device).  Uploads the circuit plan; owns only its
+ * handle and device scratch.  CSIM_ERR_NO_DEVICE if `device` is not a usable
+ * HIP device.                                                                */
+int  csim_engine_create(const csim_netlist* nl, int32_t device, csim_engine** out);
+void csim_engine_destroy(csim_engine* eng);
+/* which transient kernel the engine will use: "general" (wave-per-instance,
+ * dense LDS LU with dynamic pivoting) or "scheduled" (lane-per-instance,
+ * circuit-specialised code with a verified pivot schedule)                   */
+const char* csim_engine_tran_kernel(const csim_engine* eng);
+/* force a kernel family: 0 = auto, 1 = general only, 2 = scheduled required  */
+int  csim_engine_set_kernel(csim_engine* eng, int32_t which);
+
+/* Monte-Carlo parameter table on the device: instance b_first+i of the global
+ * batch -> column i.  Instance 0 is the nominal circuit.  Counter-based:
+ * any shard regenerates any instance from (seed, instance, slot).            */
+int  csim_mc_params_dev(csim_engine* eng, uint64_t seed, double sigma, int64_t b_first,
+                        int32_t B, double* d_params /*[P][B]*/, void* stream);
+/* host mirror of the same generator (bit-identical; for fixtures and tests)  */
+int  csim_mc_params_host(const csim_netlist* nl, uint64_t seed, double sigma, int64_t b_first,
+                         int32_t B, double* params /*[P][B]*/);
+
+/* DC operating point of B instances.                                         */
+int  csim_dc_batch_dev(csim_engine* eng, const double* d_params /*[P][B]*/, int32_t B,
+                       double* d_x /*[N][B]*/, int32_t* d_iters /*[B]*/,
+                       uint32_t* d_status /*[B]*/, void* stream);
+
+/* n_steps backward-Euler time steps for B instances, steps
+ * step_first+1 .. step_first+n_steps of the run (t = step*tstep).
+ *   d_x      in: state at step_first (the DC solution for step_first == 0);
+ *            out: state after the last step.  Histories (capacitor voltages,
+ *            inductor currents, MOS junction voltages) are functions of the
+ *            previous state, so x is the whole per-instance state.
+ *   d_wave   optional [n_rows_total][n_probe][B]: row r holds step r*out_stride
+ *            (row 0 = t=0 state, written when step_first == 0).
+ *   d_iters  [B], accumulated (+=): NR iterations.   d_status [B], OR-ed.
+ *   d_step_iters optional [n_steps][B] NR iterations of each step of this call */
+int  csim_tran_batch_dev(csim_engine* eng, const double* d_params /*[P][B]*/, int32_t B,
+                         double tstep, int64_t step_first, int64_t n_steps,
+                         const int32_t* probe_eq /*host*/, int32_t n_probe, int32_t out_stride,
+                         double* d_wave, double* d_x /*[N][B]*/, int64_t* d_iters,
+                         uint32_t* d_status, int32_t* d_step_iters, void* stream);
+
+/* Host-pointer forms.  params [B][P] instance-major (NULL =
+ * nominal for every instance), x_out/x_final [B][N].                          */
+int  csim_dc_batch(csim_engine* eng, const double* params, int32_t B,
+                   double* x_out, int32_t* nr_iters, uint32_t* status);
+/* Runs DC then the whole transient.  wave_out optional
+ * [B][n_rows][n_probe], n_rows = floor(nSteps/out_stride)+1 minus rows with
+ * t < tstart (suppressed like dumpRow, src/tanalisis.cpp:208-209).           */
+int  csim_tran_batch(csim_engine* eng, const double* params, int32_t B,
+                     double tstep, double tstop, double tstart,
+                     const int32_t* probe_eq, int32_t n_probe, int32_t out_stride,
+                     double* wave_out, double* x_final, int64_t* nr_iters, uint32_t* status);
+/* number of rows csim_tran_batch writes per instance for these numbers       */
+int64_t csim_tran_num_rows(double tstep, double tstop, double tstart, int32_t out_stride);
+int64_t csim_tran_num_steps(double tstep, double tstop);
+
+/* Batched dense solve A x = b with the engine's pivoted LU
+ * (Solver::solveLinearSystemLU semantics: first-maximum partial pivoting,
+ * tiny pivot -> zero vector).  A [B][n][n] row-major, b/x [B][n], host
+ * pointers.  flags [B] optional (CSIM_ST_LU_*).  device: HIP device index.    */
+int  csim_lu_solve_batch(int32_t device, int32_t n, int32_t B, const double* A,
+                         const double* b, double* x, uint32_t* flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSIM_H */
