@@ -1,0 +1,101 @@
+"""ctypes binding of the C-ABI in include/csim.h (libcsim.so, built in-tree).
+
+Plumbing only: every numeric result comes from the HIP kernels behind the
+C-ABI.  There is no Python or CPU arithmetic fallback; if the library is
+missing this module raises, and without a HIP device Engine() raises
+CsimError(CSIM_ERR_NO_DEVICE).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsim.so")
+
+CSIM_OK = 0
+CSIM_ERR_ARG = -1
+CSIM_ERR_IO = -2
+CSIM_ERR_NO_DEVICE = -3
+CSIM_ERR_HIP = -4
+CSIM_ERR_UNSUPPORTED = -5
+CSIM_ERR_EMPTY = -6
+CSIM_ERR_CONFIG = -7
+
+# per-instance status bits (include/csim_ir.h)
+ST_TRAN_NONFINITE = 0x0001
+ST_TRAN_NONCONV = 0x0002
+ST_LU_TINY_PIVOT = 0x0004
+ST_DC_NONCONV = 0x0008
+ST_DC_NONFINITE = 0x0010
+ST_SCHED_FALLBACK = 0x0020
+ST_LU_ZERO_DIAG = 0x0040
+
+# every symbol include/csim.h declares: name -> (restype, argtypes)
+_vp, _i32, _i64, _u64, _dbl, _cp = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double, C.c_char_p
+_pi32 = C.POINTER(C.c_int32)
+_pdbl = C.POINTER(C.c_double)
+PROTOTYPES = {
+    "csim_last_error": (_cp, []),
+    "csim_version": (_cp, []),
+    "csim_netlist_parse_file": (C.c_int, [_cp, C.POINTER(_vp)]),
+    "csim_netlist_parse_text": (C.c_int, [_cp, _i64, C.POINTER(_vp)]),
+    "csim_netlist_free": (None, [_vp]),
+    "csim_netlist_ir": (_vp, [_vp]),
+    "csim_netlist_counts": (C.c_int, [_vp, _pi32, _pi32, _pi32, _pi32, _pi32]),
+    "csim_netlist_nominal_params": (C.c_int, [_vp, _vp]),
+    "csim_netlist_eq_name": (_cp, [_vp, _i32]),
+    "csim_netlist_node_eq": (C.c_int, [_vp, _cp]),
+    "csim_netlist_tran": (C.c_int, [_vp, _pi32, _pdbl, _pdbl, _pdbl]),
+    "csim_netlist_num_probes": (C.c_int, [_vp]),
+    "csim_netlist_probe_eq": (C.c_int, [_vp, _i32]),
+    "csim_netlist_num_dc_sweeps": (C.c_int, [_vp]),
+    "csim_netlist_dc_sweep": (C.c_int, [_vp, _i32, _pi32, _pdbl, _pdbl, _pdbl]),
+    "csim_netlist_csv_header": (C.c_int, [_vp, _cp, _i32]),
+    "csim_netlist_mc_kinds": (C.c_int, [_vp, _vp]),
+    "csim_engine_create": (C.c_int, [_vp, _i32, C.POINTER(_vp)]),
+    "csim_engine_destroy": (None, [_vp]),
+    "csim_engine_tran_kernel": (_cp, [_vp]),
+    "csim_engine_set_kernel": (C.c_int, [_vp, _i32]),
+    "csim_mc_params_dev": (C.c_int, [_vp, _u64, _dbl, _i64, _i32, _vp, _vp]),
+    "csim_mc_params_host": (C.c_int, [_vp, _u64, _dbl, _i64, _i32, _vp]),
+    "csim_dc_batch_dev": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "csim_tran_batch_dev": (C.c_int, [_vp, _vp, _i32, _dbl, _i64, _i64, _vp, _i32, _i32,
+                                      _vp, _vp, _vp, _vp, _vp, _vp]),
+    "csim_dc_batch": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "csim_tran_batch": (C.c_int, [_vp, _vp, _i32, _dbl, _dbl, _dbl, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "csim_tran_num_rows": (_i64, [_dbl, _dbl, _dbl, _i32]),
+    "csim_tran_num_steps": (_i64, [_dbl, _dbl]),
+    "csim_lu_solve_batch": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+}
+
+
+class CsimError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("csim error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libcsim.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "circuitsimulator_amd: %s is missing -- build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+                "There is no fallback path." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != CSIM_OK:
+        raise CsimError(rc, lib().csim_last_error().decode("utf-8", "replace"))
+    return rc

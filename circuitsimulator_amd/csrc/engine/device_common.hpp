@@ -1,0 +1,344 @@
+// device_common.hpp -- device-side building blocks of the wave-per-instance
+// ("general") kernels: element terms, gather assembly, and the
+// wavefront-cooperative pivoted LU on an LDS-resident augmented matrix.
+//
+// One wavefront (64 lanes, one workgroup) owns one circuit instance.  The
+// dense system [G | I] lives in LDS, row-major with an ODD leading dimension
+// LD >= N+1 (8-byte words): a row walk is unit-stride and a column walk has
+// stride LD, both conflict-free over 32 banks of 8 bytes.
+//
+// Reference arithmetic restated here (ZyuRao/CircuitSimulator):
+//   mos_eval()        MosfetBase::stamp          src/element.cpp:181-307
+//   source_value_*()  SourceSpec::evalDC/evalTran, TranWaveform::eval
+//                                                include/sim.hpp:117-122,146-163
+//   lu_solve_wave()   Solver::luDecompose + solveLinearSystemLU
+//                                                include/solver.hpp:30-131
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "csim_ir.h"
+#include "plan.hpp"
+
+namespace csim {
+
+// device view of the circuit + one mode's gather lists (device pointers)
+struct GenPlan {
+    int N, LD, nNodeEq, nElem, P, nTerms, termOne, termGmin;
+    int nnzG, nnzI, hasNonlinear, pad;
+    const int32_t *kind, *eq, *branch, *slot, *wave, *termBase;
+    const int32_t *gPtr, *gPos, *gCon;
+    const int32_t *iPtr, *iRow, *iCon;
+    csim_consts k;
+};
+
+// LDS carve-up (in doubles) for one instance
+struct LdsLayout {
+    int G, T, P, xs, xp, sc, total;
+};
+__host__ __device__ inline LdsLayout ldsLayout(int N, int LD, int nTerms, int P)
+{
+    LdsLayout l;
+    l.G = 0;
+    l.T = l.G + N * LD;
+    l.P = l.T + nTerms;
+    l.xs = l.P + P;
+    l.xp = l.xs + N;
+    l.sc = l.xp + N;
+    l.total = l.sc + N;
+    return l;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+
+// one wavefront per workgroup: LDS traffic of the wave is ordered by issue, so
+// this is a wait on the LDS queue plus a scheduling fence (the s_barrier of a
+// single-wave workgroup is elided by the compiler)
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+
+// broadcast a double from a wave-uniform lane index through SGPRs
+__device__ __forceinline__ double read_lane(double v, int srcLane)
+{
+    const int l = __builtin_amdgcn_readfirstlane(srcLane);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
+    return v;
+}
+
+__device__ __forceinline__ double volt_of(const double* x, int eq) { return eq >= 0 ? x[eq] : 0.0; }
+
+// SourceSpec::evalDC (sim.hpp:152-158)
+__device__ __forceinline__ double source_value_dc(const double* Pv, int slot, int wave, double scale)
+{
+    double base = Pv[slot + 0];
+    if (wave == CSIM_WAVE_SIN) base += Pv[slot + 1];
+    return base * scale;
+}
+
+// SourceSpec::evalTran (sim.hpp:160-162) with TranWaveform::eval SIN (:117-122)
+__device__ __forceinline__ double source_value_tran(const double* Pv, int slot, int wave, double t, double pi)
+{
+    const double dc = Pv[slot + 0];
+    double w = 0.0;
+    if (wave == CSIM_WAVE_SIN) {
+        const double v0 = Pv[slot + 1], va = Pv[slot + 2], freq = Pv[slot + 3];
+        const double td = Pv[slot + 4], phi = Pv[slot + 5];
+        if (t < td) w = v0;
+        else {
+            const double tau = t - td;
+            const double om = 2.0 * pi * freq;
+            w = v0 + va * sin(om * tau + phi);
+        }
+    }
+    return dc + w;
+}
+
+// Level-1 MOSFET linearisation at (Vd, Vg, Vs): MosfetBase::stamp, element.cpp:207-274
+struct MosLin { double gd, gg, gs, cst; };
+__device__ __forceinline__ MosLin mos_eval(bool isP, double Vth, double K, double lambda, double offGds,
+                                           double Vd, double Vg, double Vs)
+{
+    const double p = isP ? -1.0 : 1.0;
+    const double Vgs = p * (Vg - Vs);
+    const double Vds = p * (Vd - Vs);
+    double Ids0 = 0.0, gds0 = offGds, gm0 = 0.0;        // off state (:245-252)
+    if (Vgs > Vth && Vds >= 0.0) {                      // (:223)
+        const double Vov = Vgs - Vth;
+        if (Vds < Vov) {                                // triode (:232-236)
+            Ids0 = K * (Vov * Vds - 0.5 * Vds * Vds);
+            gds0 = K * (Vov - Vds);
+            gm0  = K * Vds;
+        } else {                                        // saturation (:239-241)
+            Ids0 = 0.5 * K * Vov * Vov;
+            gds0 = 0.0;
+            gm0  = K * Vov;
+        }
+    }
+    double factor = 1.0 + lambda * Vds;                 // (:255-256)
+    if (factor < 0.0) factor = 0.0;
+    const double Ids = p * (Ids0 * factor);             // (:257,266)
+    MosLin r;
+    r.gd = gds0 * factor + Ids0 * lambda;               // (:260,269)
+    r.gg = gm0 * factor;                                // (:263,270)
+    r.gs = -(r.gd + r.gg);                              // (:271)
+    r.cst = Ids - r.gd * Vd - r.gg * Vg - r.gs * Vs;    // (:274)
+    return r;
+}
+
+// ---- terms that stay constant over a launch
+template <bool TRAN>
+__device__ __forceinline__ void terms_const(const GenPlan& pl, const double* Pv, double* T, double dt, int lane)
+{
+    for (int e = lane; e < pl.nElem; e += 64) {
+        const int kind = pl.kind[e], s = pl.slot[e], tb = pl.termBase[e];
+        if (kind == CSIM_R) {
+            const double R = Pv[s];
+            T[tb + T_R_G] = (R == 0.0) ? 0.0 : 1.0 / R;            // element.cpp:20-24
+        } else if (TRAN && kind == CSIM_C) {
+            const double C = Pv[s];
+            T[tb + T_C_GC] = (C > 0.0 && dt > 0.0) ? C / dt : 0.0; // tanalisis.cpp:65-67
+            T[tb + T_C_IH] = 0.0;
+        } else if (TRAN && kind == CSIM_L) {
+            const double L = Pv[s];
+            const bool on = L > 0.0;                               // tanalisis.cpp:296
+            T[tb + T_L_REQ] = on ? L / dt : 0.0;
+            T[tb + T_L_VH] = 0.0;
+            T[tb + T_L_ONE] = on ? 1.0 : 0.0;
+        } else if (TRAN && (kind == CSIM_NMOS || kind == CSIM_PMOS)) {
+            const double Cj0 = Pv[s + 3];
+            const double Ch = 0.5 * Cj0;                           // tanalisis.cpp:337-341
+            T[tb + T_M_GCH] = (Ch > 0.0 && dt > 0.0) ? Ch / dt : 0.0;
+            T[tb + T_M_GCF] = (Cj0 > 0.0 && dt > 0.0) ? Cj0 / dt : 0.0;
+        }
+    }
+    if (lane == 0) T[pl.termOne] = 1.0;
+}
+
+// ---- terms that change once per time step: sources and history currents
+__device__ __forceinline__ void terms_step_tran(const GenPlan& pl, const double* Pv, double* T,
+                                                const double* xp, double t, int lane)
+{
+    for (int e = lane; e < pl.nElem; e += 64) {
+        const int kind = pl.kind[e], s = pl.slot[e], tb = pl.termBase[e];
+        const int32_t* q = pl.eq + 4 * e;
+        if (kind == CSIM_V || kind == CSIM_I) {
+            T[tb + T_SRC_VAL] = source_value_tran(Pv, s, pl.wave[e], t, pl.k.pi);
+        } else if (kind == CSIM_C) {
+            const double vPrev = volt_of(xp, q[0]) - volt_of(xp, q[1]);
+            T[tb + T_C_IH] = -T[tb + T_C_GC] * vPrev;              // tanalisis.cpp:77
+        } else if (kind == CSIM_L) {
+            const int k = pl.branch[e];
+            const double iPrev = (k >= 0 && k < pl.N) ? xp[k] : 0.0;
+            T[tb + T_L_VH] = -T[tb + T_L_REQ] * iPrev;             // tanalisis.cpp:308
+        } else if (kind == CSIM_NMOS || kind == CSIM_PMOS) {
+            const double vD = volt_of(xp, q[0]), vG = volt_of(xp, q[1]);
+            const double vS = volt_of(xp, q[2]), vB = volt_of(xp, q[3]);
+            const double gh = T[tb + T_M_GCH], gf = T[tb + T_M_GCF];
+            T[tb + T_M_IHGS] = -gh * (vG - vS);
+            T[tb + T_M_IHGD] = -gh * (vG - vD);
+            T[tb + T_M_IHSB] = -gf * (vS - vB);
+            T[tb + T_M_IHDB] = -gf * (vD - vB);
+        }
+    }
+}
+
+__device__ __forceinline__ void terms_step_dc(const GenPlan& pl, const double* Pv, double* T, double scale, int lane)
+{
+    for (int e = lane; e < pl.nElem; e += 64) {
+        const int kind = pl.kind[e];
+        if (kind == CSIM_V || kind == CSIM_I)
+            T[pl.termBase[e] + T_SRC_VAL] = source_value_dc(Pv, pl.slot[e], pl.wave[e], scale);
+    }
+}
+
+// ---- terms that change every Newton iteration: MOS channel at the iterate x
+__device__ __forceinline__ void terms_iter_mos(const GenPlan& pl, const double* Pv, double* T, const double* x, int lane)
+{
+    for (int e = lane; e < pl.nElem; e += 64) {
+        const int kind = pl.kind[e];
+        if (kind != CSIM_NMOS && kind != CSIM_PMOS) continue;
+        const int s = pl.slot[e], tb = pl.termBase[e];
+        const int32_t* q = pl.eq + 4 * e;
+        const MosLin m = mos_eval(kind == CSIM_PMOS, Pv[s + 0], Pv[s + 1], Pv[s + 2], pl.k.mos_off_gds,
+                                  volt_of(x, q[0]), volt_of(x, q[1]), volt_of(x, q[2]));
+        T[tb + T_M_GD] = m.gd;
+        T[tb + T_M_GG] = m.gg;
+        T[tb + T_M_GS] = m.gs;
+        T[tb + T_M_CST] = m.cst;
+    }
+}
+
+// ---- build [G | I] in LDS: clear, then every structural non-zero sums its
+// terms in the reference's accumulation order
+__device__ __forceinline__ void assemble(const GenPlan& pl, const double* T, double* Gm, int lane)
+{
+    const int total = pl.N * pl.LD;
+    for (int i = lane; i < total; i += 64) Gm[i] = 0.0;
+    wave_sync();
+    for (int n = lane; n < pl.nnzG; n += 64) {
+        double acc = 0.0;
+        for (int c = pl.gPtr[n]; c < pl.gPtr[n + 1]; ++c) {
+            const int con = pl.gCon[c];
+            const double v = T[con >> 1];
+            acc = (con & 1) ? acc - v : acc + v;
+        }
+        Gm[pl.gPos[n]] = acc;
+    }
+    for (int n = lane; n < pl.nnzI; n += 64) {
+        double acc = 0.0;
+        for (int c = pl.iPtr[n]; c < pl.iPtr[n + 1]; ++c) {
+            const int con = pl.iCon[c];
+            const double v = T[con >> 1];
+            acc = (con & 1) ? acc - v : acc + v;
+        }
+        Gm[pl.iRow[n] * pl.LD + pl.N] = acc;
+    }
+    wave_sync();
+}
+
+// ---- wavefront-cooperative LU with partial pivoting + substitution on the
+// augmented LDS matrix (N <= 63: row i and column j are owned by lane i / j,
+// the RHS is column N).
+//
+// Same pivot rule as Solver::luDecompose: the FIRST row attaining the column
+// maximum (solver.hpp:48-56, strict '>'), failure if that maximum is < eps
+// (:58-61) -> zero solution vector (:94-97).  Forward substitution is fused
+// into the elimination by carrying the RHS column (identical operation order
+// per row: multipliers are applied in ascending k).  Rows whose multiplier is
+// exactly zero are skipped: a - 0*b == a, so this is bit-identical while the
+// matrix is ~10 % dense.  Back substitution is column-oriented (lane i
+// updates y_i as each x_j becomes known, j descending); the reference sums
+// row-wise in ascending j, so the two differ by rounding only.
+//
+// Returns the solution component of lane i (< N) and ORs CSIM_ST_LU_* flags.
+__device__ __forceinline__ double lu_solve_wave(double* Gm, int N, int LD, double eps, int lane, unsigned& flags)
+{
+    double diag = 1.0;          // lane k keeps U(k,k)
+    bool failed = false;
+
+    for (int k = 0; k < N; ++k) {
+        // column k below and including the diagonal: lane i holds a(i,k)
+        double colv = (lane < N) ? Gm[lane * LD + k] : 0.0;
+        const double av = fabs(colv);
+        const double akk = read_lane(av, k);
+        int piv = k;
+        double maxAbs = akk;
+        if (akk == akk) {       // a NaN diagonal keeps pivot = k in the reference
+            const double cand = (lane >= k && lane < N && av == av) ? av : -1.0;
+            maxAbs = wave_max(cand);
+            const unsigned long long hit = __ballot(cand == maxAbs);
+            piv = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
+        }
+        if (maxAbs < eps) { failed = true; break; }
+
+        if (piv != k) {         // swap rows k and piv (columns >= k and the RHS)
+            if (lane >= k && lane <= N) {
+                const double a = Gm[k * LD + lane], b = Gm[piv * LD + lane];
+                Gm[k * LD + lane] = b;
+                Gm[piv * LD + lane] = a;
+            }
+            const double ck = read_lane(colv, k), cp = read_lane(colv, piv);
+            if (lane == k) colv = cp;
+            if (lane == piv) colv = ck;
+            wave_sync();
+        }
+
+        const double pivv = read_lane(colv, k);
+        if (lane == k) diag = pivv;
+        // lane j holds the pivot row entry a(k,j), j in (k, N]
+        const double rowv = (lane > k && lane <= N) ? Gm[k * LD + lane] : 0.0;
+
+        unsigned long long todo = __ballot(lane > k && lane < N && colv != 0.0);
+        while (todo) {
+            const int i = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const double f = read_lane(colv, i) / pivv;             // solver.hpp:71
+            if (lane > k && lane <= N) Gm[i * LD + lane] -= f * rowv;   // :74 (+ RHS)
+        }
+        wave_sync();
+    }
+
+    if (failed) {
+        flags |= CSIM_ST_LU_TINY_PIVOT;
+        return 0.0;
+    }
+
+    // back substitution, solver.hpp:116-128
+    double y = (lane < N) ? Gm[lane * LD + N] : 0.0;
+    double xv = 0.0;
+    for (int j = N - 1; j >= 0; --j) {
+        const double d = read_lane(diag, j);
+        const double yj = read_lane(y, j);
+        double xj;
+        if (fabs(d) < eps) { xj = 0.0; flags |= CSIM_ST_LU_ZERO_DIAG; }
+        else xj = yj / d;
+        if (lane == j) xv = xj;
+        if (lane < j) y -= Gm[lane * LD + j] * xj;
+    }
+    return xv;
+}
+
+// ||v||_2 with the squares summed in index order 0..N-1 (the order of the
+// oracle's norm); sc is an N-double LDS scratch
+__device__ __forceinline__ double norm_in_order(double d, double* sc, int N, int lane)
+{
+    if (lane < N) sc[lane] = d * d;
+    wave_sync();
+    double ss = 0.0;
+    for (int i = 0; i < N; ++i) ss += sc[i];
+    wave_sync();
+    return sqrt(ss);
+}
+
+#endif // device
+
+} // namespace csim

@@ -1,0 +1,380 @@
+// engine.cpp -- C-ABI of the HIP engine: handle, device-side circuit plan,
+// batch entry points.  No CPU arithmetic path exists here: without a usable
+// HIP device csim_engine_create fails (CSIM_ERR_NO_DEVICE).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "csim.h"
+#include "engine_internal.hpp"
+#include "kernels.hpp"
+#include "netlist_internal.hpp"
+#include "plan.hpp"
+
+using csim::setError;
+
+#define HIPCHK(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            setError(std::string(#call) + ": " + hipGetErrorString(e_));               \
+            return CSIM_ERR_HIP;                                                       \
+        }                                                                              \
+    } while (0)
+
+namespace {
+
+template <class T>
+int upload(csim_engine* eng, const std::vector<T>& host, const T** out)
+{
+    void* d = nullptr;
+    const size_t bytes = sizeof(T) * (host.empty() ? 1 : host.size());
+    HIPCHK(hipMalloc(&d, bytes));
+    eng->owned.push_back(d);
+    if (!host.empty()) HIPCHK(hipMemcpy(d, host.data(), sizeof(T) * host.size(), hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(d);
+    return CSIM_OK;
+}
+
+int fillGenPlan(csim_engine* eng, const csim::GatherPlan& g, csim::GenPlan& out)
+{
+    const csim_ir* ir = eng->cir.view();
+    const csim::AssemblyPlan& ap = eng->plan;
+    out.N = ap.N;
+    out.LD = ap.LD;
+    out.nNodeEq = ir->n_node_eq;
+    out.nElem = ir->n_elems;
+    out.P = ir->n_params;
+    out.nTerms = ap.nTerms;
+    out.termOne = ap.termOne;
+    out.termGmin = ap.termGmin;
+    out.nnzG = g.nnzG();
+    out.nnzI = g.nnzI();
+    out.hasNonlinear = ir->has_nonlinear;
+    out.pad = 0;
+    out.kind = eng->dKind; out.eq = eng->dEq; out.branch = eng->dBranch;
+    out.slot = eng->dSlot; out.wave = eng->dWave; out.termBase = eng->dTermBase;
+    int rc;
+    if ((rc = upload(eng, g.gPtr, &out.gPtr))) return rc;
+    if ((rc = upload(eng, g.gPos, &out.gPos))) return rc;
+    if ((rc = upload(eng, g.gCon, &out.gCon))) return rc;
+    if ((rc = upload(eng, g.iPtr, &out.iPtr))) return rc;
+    if ((rc = upload(eng, g.iRow, &out.iRow))) return rc;
+    if ((rc = upload(eng, g.iCon, &out.iCon))) return rc;
+    out.k = ir->k;
+    return CSIM_OK;
+}
+
+// scratch allocation that frees itself
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+int ensureProbes(csim_engine* eng, const int32_t* probe_eq, int n_probe, const int32_t** dOut)
+{
+    *dOut = nullptr;
+    if (n_probe <= 0) return CSIM_OK;
+    if (!probe_eq) { setError("probe_eq is null but n_probe > 0"); return CSIM_ERR_ARG; }
+    const int N = eng->plan.N;
+    for (int i = 0; i < n_probe; ++i)
+        if (probe_eq[i] < 0 || probe_eq[i] >= N) { setError("probe equation index out of range"); return CSIM_ERR_ARG; }
+    if (n_probe > 64) { setError("at most 64 probes per launch"); return CSIM_ERR_UNSUPPORTED; }
+    std::vector<int32_t> want(probe_eq, probe_eq + n_probe);
+    if (want != eng->probeCache) {
+        if (!eng->dProbe) {
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dProbe), sizeof(int32_t) * 64));
+            eng->owned.push_back(eng->dProbe);
+        }
+        HIPCHK(hipMemcpy(eng->dProbe, want.data(), sizeof(int32_t) * want.size(), hipMemcpyHostToDevice));
+        eng->probeCache = want;
+    }
+    *dOut = eng->dProbe;
+    return CSIM_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int csim_engine_create(const csim_netlist* nl, int32_t device, csim_engine** out)
+{
+    if (!nl || !out) { setError("csim_engine_create: null argument"); return CSIM_ERR_ARG; }
+    *out = nullptr;
+    int count = 0;
+    const hipError_t ce = hipGetDeviceCount(&count);
+    if (ce != hipSuccess || count <= 0 || device < 0 || device >= count) {
+        setError("csim_engine_create: no usable HIP device (this library has no CPU path)");
+        return CSIM_ERR_NO_DEVICE;
+    }
+    const csim_ir* ir = nl->cir.view();
+    if (ir->n_unknowns <= 0) { setError("circuit has no unknowns"); return CSIM_ERR_EMPTY; }
+    if (ir->n_unknowns > 63) {
+        setError("general kernels cover N <= 63 unknowns");
+        return CSIM_ERR_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(device));
+
+    auto* eng = new csim_engine();
+    eng->device = device;
+    eng->cir = nl->cir;
+    eng->cir.view();
+    eng->plan = csim::buildAssemblyPlan(*eng->cir.view());
+
+    int rc = CSIM_OK;
+    const csim::CircuitIR& c = eng->cir;
+    if (!rc) rc = upload(eng, c.kind, &eng->dKind);
+    if (!rc) rc = upload(eng, c.eq, &eng->dEq);
+    if (!rc) rc = upload(eng, c.branchEq, &eng->dBranch);
+    if (!rc) rc = upload(eng, c.paramSlot, &eng->dSlot);
+    if (!rc) rc = upload(eng, c.wave, &eng->dWave);
+    if (!rc) rc = upload(eng, eng->plan.termBase, &eng->dTermBase);
+    if (!rc) rc = upload(eng, c.mcKind, &eng->dMcKind);
+    if (!rc) rc = upload(eng, c.nominal, &eng->dNominal);
+    if (!rc) rc = upload(eng, c.mcMu, &eng->dMu);
+    if (!rc) rc = upload(eng, c.mcCox, &eng->dCox);
+    if (!rc) rc = upload(eng, c.mcW, &eng->dW);
+    if (!rc) rc = upload(eng, c.mcL, &eng->dL);
+    if (!rc) rc = fillGenPlan(eng, eng->plan.dc, eng->gpDc);
+    if (!rc) rc = fillGenPlan(eng, eng->plan.tran, eng->gpTran);
+    if (rc) { csim_engine_destroy(eng); return rc; }
+    *out = eng;
+    return CSIM_OK;
+}
+
+void csim_engine_destroy(csim_engine* eng)
+{
+    if (!eng) return;
+    (void)hipSetDevice(eng->device);
+    for (void* p : eng->owned) (void)hipFree(p);
+    delete eng;
+}
+
+const char* csim_engine_tran_kernel(const csim_engine* eng)
+{
+    if (!eng) return "";
+    return "general";
+}
+
+int csim_engine_set_kernel(csim_engine* eng, int32_t which)
+{
+    if (!eng || which < 0 || which > 2) return CSIM_ERR_ARG;
+    if (which == 2) { setError("no scheduled kernel is available for this circuit"); return CSIM_ERR_UNSUPPORTED; }
+    eng->kernelChoice = which;
+    return CSIM_OK;
+}
+
+int csim_mc_params_dev(csim_engine* eng, uint64_t seed, double sigma, int64_t b_first,
+                       int32_t B, double* d_params, void* stream)
+{
+    if (!eng || !d_params || B < 0 || b_first < 0) { setError("csim_mc_params_dev: bad argument"); return CSIM_ERR_ARG; }
+    HIPCHK(hipSetDevice(eng->device));
+    HIPCHK(csim::launchMcParams(eng->cir.ir.n_params, B, b_first, seed, sigma, eng->dMcKind, eng->dNominal,
+                                eng->dMu, eng->dCox, eng->dW, eng->dL, d_params,
+                                static_cast<hipStream_t>(stream)));
+    return CSIM_OK;
+}
+
+int csim_dc_batch_dev(csim_engine* eng, const double* d_params, int32_t B, double* d_x,
+                      int32_t* d_iters, uint32_t* d_status, void* stream)
+{
+    if (!eng || !d_params || !d_x || !d_iters || !d_status || B < 0) {
+        setError("csim_dc_batch_dev: bad argument");
+        return CSIM_ERR_ARG;
+    }
+    if (B == 0) return CSIM_OK;
+    HIPCHK(hipSetDevice(eng->device));
+    HIPCHK(csim::launchDcGeneral(eng->gpDc, d_params, B, d_x, d_iters, d_status, static_cast<hipStream_t>(stream)));
+    return CSIM_OK;
+}
+
+int csim_tran_batch_dev(csim_engine* eng, const double* d_params, int32_t B, double tstep,
+                        int64_t step_first, int64_t n_steps, const int32_t* probe_eq, int32_t n_probe,
+                        int32_t out_stride, double* d_wave, double* d_x, int64_t* d_iters,
+                        uint32_t* d_status, int32_t* d_step_iters, void* stream)
+{
+    if (!eng || !d_params || !d_x || !d_iters || !d_status || B < 0 || step_first < 0 || n_steps < 0) {
+        setError("csim_tran_batch_dev: bad argument");
+        return CSIM_ERR_ARG;
+    }
+    if (!(tstep > 0.0)) { setError("tstep must be > 0"); return CSIM_ERR_CONFIG; }
+    if (step_first + n_steps > 2147483647LL) { setError("step index exceeds int range of the reference"); return CSIM_ERR_CONFIG; }
+    if (B == 0) return CSIM_OK;
+    HIPCHK(hipSetDevice(eng->device));
+    const int32_t* dProbe = nullptr;
+    if (d_wave) {
+        if (out_stride <= 0) { setError("out_stride must be >= 1"); return CSIM_ERR_ARG; }
+        const int rc = ensureProbes(eng, probe_eq, n_probe, &dProbe);
+        if (rc) return rc;
+    }
+    HIPCHK(csim::launchTranGeneral(eng->gpTran, d_params, B, tstep, step_first, n_steps, dProbe,
+                                   d_wave ? n_probe : 0, d_wave ? out_stride : 1, d_wave, d_x,
+                                   reinterpret_cast<long long*>(d_iters), d_status, d_step_iters, nullptr,
+                                   static_cast<hipStream_t>(stream)));
+    return CSIM_OK;
+}
+
+int64_t csim_tran_num_steps(double tstep, double tstop)
+{
+    if (!(tstep > 0.0) || !(tstop > 0.0)) return -1;
+    return static_cast<int64_t>(static_cast<int>(std::floor(tstop / tstep + 1e-12)));   // tanalisis.cpp:238
+}
+
+int64_t csim_tran_num_rows(double tstep, double tstop, double tstart, int32_t out_stride)
+{
+    const int64_t ns = csim_tran_num_steps(tstep, tstop);
+    if (ns < 0 || out_stride <= 0) return -1;
+    int64_t rows = 0;
+    for (int64_t r = 0; r <= ns / out_stride; ++r) {
+        const double t = (r == 0) ? 0.0 : static_cast<double>(static_cast<int>(r * out_stride)) * tstep;
+        if (!(t < tstart)) ++rows;                                                       // tanalisis.cpp:209
+    }
+    return rows;
+}
+
+// ---- host-pointer forms ---------------------------------------------------
+
+static int stageParams(csim_engine* eng, const double* params, int B, DevBuf& dParams)
+{
+    const int P = eng->cir.ir.n_params;
+    HIPCHK(dParams.alloc(sizeof(double) * (size_t)P * (size_t)B));
+    if (params) {
+        DevBuf tmp;
+        HIPCHK(tmp.alloc(sizeof(double) * (size_t)P * (size_t)B));
+        HIPCHK(hipMemcpy(tmp.p, params, sizeof(double) * (size_t)P * (size_t)B, hipMemcpyHostToDevice));
+        HIPCHK(csim::launchTranspose(tmp.as<double>(), dParams.as<double>(), B, P, nullptr));   // [B][P] -> [P][B]
+        HIPCHK(hipDeviceSynchronize());
+    } else {
+        std::vector<double> rep((size_t)P * (size_t)B);
+        for (int p = 0; p < P; ++p)
+            for (int b = 0; b < B; ++b) rep[(size_t)p * B + b] = eng->cir.nominal[(size_t)p];
+        HIPCHK(hipMemcpy(dParams.p, rep.data(), sizeof(double) * rep.size(), hipMemcpyHostToDevice));
+    }
+    return CSIM_OK;
+}
+
+int csim_dc_batch(csim_engine* eng, const double* params, int32_t B, double* x_out,
+                  int32_t* nr_iters, uint32_t* status)
+{
+    if (!eng || B < 0) { setError("csim_dc_batch: bad argument"); return CSIM_ERR_ARG; }
+    if (B == 0) return CSIM_OK;
+    HIPCHK(hipSetDevice(eng->device));
+    const int N = eng->plan.N;
+    DevBuf dParams, dX, dXt, dIt, dSt;
+    int rc = stageParams(eng, params, B, dParams);
+    if (rc) return rc;
+    HIPCHK(dX.alloc(sizeof(double) * (size_t)N * B));
+    HIPCHK(dXt.alloc(sizeof(double) * (size_t)N * B));
+    HIPCHK(dIt.alloc(sizeof(int32_t) * (size_t)B));
+    HIPCHK(dSt.alloc(sizeof(uint32_t) * (size_t)B));
+    rc = csim_dc_batch_dev(eng, dParams.as<double>(), B, dX.as<double>(), dIt.as<int32_t>(), dSt.as<uint32_t>(), nullptr);
+    if (rc) return rc;
+    HIPCHK(csim::launchTranspose(dX.as<double>(), dXt.as<double>(), N, B, nullptr));            // [N][B] -> [B][N]
+    HIPCHK(hipDeviceSynchronize());
+    if (x_out)    HIPCHK(hipMemcpy(x_out, dXt.p, sizeof(double) * (size_t)N * B, hipMemcpyDeviceToHost));
+    if (nr_iters) HIPCHK(hipMemcpy(nr_iters, dIt.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost));
+    if (status)   HIPCHK(hipMemcpy(status, dSt.p, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost));
+    return CSIM_OK;
+}
+
+int csim_tran_batch(csim_engine* eng, const double* params, int32_t B, double tstep, double tstop,
+                    double tstart, const int32_t* probe_eq, int32_t n_probe, int32_t out_stride,
+                    double* wave_out, double* x_final, int64_t* nr_iters, uint32_t* status)
+{
+    if (!eng || B < 0) { setError("csim_tran_batch: bad argument"); return CSIM_ERR_ARG; }
+    if (!(tstep > 0.0) || !(tstop > 0.0)) {                     // tanalisis.cpp:94-97
+        setError("Invalid .TRAN card: tstep and tstop must be > 0");
+        return CSIM_ERR_CONFIG;
+    }
+    if (wave_out && (out_stride <= 0 || n_probe <= 0 || !probe_eq)) { setError("csim_tran_batch: bad probe arguments"); return CSIM_ERR_ARG; }
+    if (B == 0) return CSIM_OK;
+    HIPCHK(hipSetDevice(eng->device));
+    const int N = eng->plan.N;
+    const int64_t nSteps = csim_tran_num_steps(tstep, tstop);
+    const int64_t rowsAll = wave_out ? nSteps / out_stride + 1 : 0;
+
+    DevBuf dParams, dX, dXt, dIt32, dIt, dSt, dWave, dWaveT;
+    int rc = stageParams(eng, params, B, dParams);
+    if (rc) return rc;
+    HIPCHK(dX.alloc(sizeof(double) * (size_t)N * B));
+    HIPCHK(dXt.alloc(sizeof(double) * (size_t)N * B));
+    HIPCHK(dIt32.alloc(sizeof(int32_t) * (size_t)B));
+    HIPCHK(dIt.alloc(sizeof(int64_t) * (size_t)B));
+    HIPCHK(dSt.alloc(sizeof(uint32_t) * (size_t)B));
+    HIPCHK(hipMemset(dIt.p, 0, sizeof(int64_t) * (size_t)B));
+    const size_t waveElems = (size_t)rowsAll * (size_t)(wave_out ? n_probe : 0) * (size_t)B;
+    if (wave_out) {
+        HIPCHK(dWave.alloc(sizeof(double) * waveElems));
+        HIPCHK(hipMemset(dWave.p, 0, sizeof(double) * waveElems));
+    }
+
+    // t = 0 state: the DC operating point (tanalisis.cpp:112); its status bits stay in dSt
+    rc = csim_dc_batch_dev(eng, dParams.as<double>(), B, dX.as<double>(), dIt32.as<int32_t>(), dSt.as<uint32_t>(), nullptr);
+    if (rc) return rc;
+    // time stepping in bounded launches (state carried in dX)
+    const int64_t chunk = 4096;
+    for (int64_t s0 = 0; s0 < nSteps || s0 == 0; s0 += chunk) {
+        const int64_t n = (nSteps - s0) < chunk ? (nSteps - s0) : chunk;
+        rc = csim_tran_batch_dev(eng, dParams.as<double>(), B, tstep, s0, n, probe_eq, n_probe, out_stride,
+                                 wave_out ? dWave.as<double>() : nullptr, dX.as<double>(), dIt.as<int64_t>(),
+                                 dSt.as<uint32_t>(), nullptr, nullptr);
+        if (rc) return rc;
+        if (nSteps == 0) break;
+    }
+    HIPCHK(csim::launchTranspose(dX.as<double>(), dXt.as<double>(), N, B, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    if (x_final)  HIPCHK(hipMemcpy(x_final, dXt.p, sizeof(double) * (size_t)N * B, hipMemcpyDeviceToHost));
+    if (nr_iters) HIPCHK(hipMemcpy(nr_iters, dIt.p, sizeof(int64_t) * (size_t)B, hipMemcpyDeviceToHost));
+    if (status)   HIPCHK(hipMemcpy(status, dSt.p, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost));
+
+    if (wave_out) {
+        // device [rows][probe][B] -> host [B][rows][probe], dropping rows with t < tstart
+        std::vector<double> h(waveElems);
+        HIPCHK(hipMemcpy(h.data(), dWave.p, sizeof(double) * waveElems, hipMemcpyDeviceToHost));
+        int64_t firstKept = 0;
+        for (int64_t r = 0; r < rowsAll; ++r) {
+            const double t = (r == 0) ? 0.0 : static_cast<double>(static_cast<int>(r * out_stride)) * tstep;
+            if (t < tstart) firstKept = r + 1; else break;
+        }
+        const int64_t keep = rowsAll - firstKept;
+        for (int64_t b = 0; b < B; ++b)
+            for (int64_t r = 0; r < keep; ++r)
+                for (int q = 0; q < n_probe; ++q)
+                    wave_out[(b * keep + r) * n_probe + q] = h[((size_t)(r + firstKept) * n_probe + q) * B + b];
+    }
+    return CSIM_OK;
+}
+
+int csim_lu_solve_batch(int32_t device, int32_t n, int32_t B, const double* A, const double* b,
+                        double* x, uint32_t* flags)
+{
+    if (n < 0 || B < 0 || !x || (n > 0 && B > 0 && (!A || !b))) { setError("csim_lu_solve_batch: bad argument"); return CSIM_ERR_ARG; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {
+        setError("csim_lu_solve_batch: no usable HIP device (this library has no CPU path)");
+        return CSIM_ERR_NO_DEVICE;
+    }
+    if (n == 0 || B == 0) return CSIM_OK;              // solver.hpp:86: empty system -> empty vector
+    if (n > 63) { setError("csim_lu_solve_batch covers n <= 63"); return CSIM_ERR_UNSUPPORTED; }
+    HIPCHK(hipSetDevice(device));
+    DevBuf dA, dB, dX, dF;
+    HIPCHK(dA.alloc(sizeof(double) * (size_t)n * n * B));
+    HIPCHK(dB.alloc(sizeof(double) * (size_t)n * B));
+    HIPCHK(dX.alloc(sizeof(double) * (size_t)n * B));
+    HIPCHK(dF.alloc(sizeof(uint32_t) * (size_t)B));
+    HIPCHK(hipMemcpy(dA.p, A, sizeof(double) * (size_t)n * n * B, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dB.p, b, sizeof(double) * (size_t)n * B, hipMemcpyHostToDevice));
+    HIPCHK(csim::launchLuSolve(n, B, dA.as<double>(), dB.as<double>(), dX.as<double>(), dF.as<uint32_t>(), 1e-15, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(x, dX.p, sizeof(double) * (size_t)n * B, hipMemcpyDeviceToHost));
+    if (flags) HIPCHK(hipMemcpy(flags, dF.p, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost));
+    return CSIM_OK;
+}
+
+} // extern "C"

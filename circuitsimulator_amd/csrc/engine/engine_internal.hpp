@@ -1,0 +1,31 @@
+// engine_internal.hpp -- what a csim_engine handle holds (library-private).
+#pragma once
+
+#include <stdint.h>
+#include <vector>
+
+#include "../api/circuit.hpp"
+#include "device_common.hpp"
+#include "plan.hpp"
+
+struct csim_engine {
+    int device = 0;
+    int kernelChoice = 0;                  // 0 auto, 1 general, 2 scheduled
+    csim::CircuitIR cir;                   // private copy of the flattened circuit
+    csim::AssemblyPlan plan;
+
+    std::vector<void*> owned;              // every device allocation, freed on destroy
+
+    // element tables (shared by both gather plans)
+    const int32_t *dKind = nullptr, *dEq = nullptr, *dBranch = nullptr, *dSlot = nullptr,
+                  *dWave = nullptr, *dTermBase = nullptr;
+    csim::GenPlan gpDc{}, gpTran{};
+
+    // Monte-Carlo recipe
+    const int32_t* dMcKind = nullptr;
+    const double *dNominal = nullptr, *dMu = nullptr, *dCox = nullptr, *dW = nullptr, *dL = nullptr;
+
+    // probe list of the most recent transient call
+    int32_t* dProbe = nullptr;
+    std::vector<int32_t> probeCache;
+};

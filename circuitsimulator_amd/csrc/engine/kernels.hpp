@@ -1,0 +1,32 @@
+// kernels.hpp -- host-callable launchers of the HIP kernels (library-private).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_common.hpp"
+
+namespace csim {
+
+// wave-per-instance kernels (kernels_general.hip)
+hipError_t launchDcGeneral(const GenPlan& pl, const double* dParams, int B, double* dX,
+                           int32_t* dIters, uint32_t* dStatus, hipStream_t stream);
+hipError_t launchTranGeneral(const GenPlan& pl, const double* dParams, int B, double dt,
+                             long long stepFirst, long long nSteps, const int32_t* dProbeEq, int nProbe,
+                             int outStride, double* dWave, double* dX, long long* dIters,
+                             uint32_t* dStatus, int32_t* dStepIters, const uint8_t* dOnly,
+                             hipStream_t stream);
+hipError_t launchLuSolve(int n, int B, const double* dA, const double* dRhs, double* dX,
+                         uint32_t* dFlags, double eps, hipStream_t stream);
+size_t generalLdsBytes(const GenPlan& pl);
+
+// Monte-Carlo parameter table (mc.hip)
+hipError_t launchMcParams(int P, int B, long long bFirst, uint64_t seed, double sigma,
+                          const int32_t* dKind, const double* dNominal, const double* dMu,
+                          const double* dCox, const double* dW, const double* dL,
+                          double* dParams, hipStream_t stream);
+
+// layout helpers (transpose.hip): [rows][cols] <-> [cols][rows] of doubles
+hipError_t launchTranspose(const double* dIn, double* dOut, int rows, int cols, hipStream_t stream);
+
+} // namespace csim

@@ -1,0 +1,231 @@
+"""Host-side mirror of the reference's analysis interface over the C-ABI.
+
+Netlist  ~ parseNetlist() + Circuit::assignEquationIndices()   (src/main.cpp:29,34)
+Engine.dc    ~ computeDcOperatingPoint()                       (include/tanalisis.hpp:9)
+Engine.tran  ~ runTransientAnalysisBackwardEuler()             (include/tanalisis.hpp:15-17)
+lu_solve_batch ~ Solver::solveLinearSystemLU()                 (include/solver.hpp:83-131)
+
+for a BATCH of instances.  torch is used for device memory and streams only;
+all arithmetic happens in the HIP kernels behind include/csim.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class Netlist:
+    """A parsed, indexed and flattened netlist (host only)."""
+
+    def __init__(self, handle, source=None):
+        self._h = handle
+        self.source = source
+        L = capi.lib()
+        c = [C.c_int32() for _ in range(5)]
+        capi.check(L.csim_netlist_counts(self._h, *[C.byref(v) for v in c]))
+        self.n_nodes, self.n_elems, self.n_unknowns, self.n_node_eq, self.n_branch_eq = [v.value for v in c]
+        self.eq_names = [L.csim_netlist_eq_name(self._h, i).decode() for i in range(self.n_unknowns)]
+        en, ts, tp, t0 = C.c_int32(), C.c_double(), C.c_double(), C.c_double()
+        capi.check(L.csim_netlist_tran(self._h, C.byref(en), C.byref(ts), C.byref(tp), C.byref(t0)))
+        self.tran_enabled, self.tstep, self.tstop, self.tstart = bool(en.value), ts.value, tp.value, t0.value
+        self.probes = [L.csim_netlist_probe_eq(self._h, i) for i in range(L.csim_netlist_num_probes(self._h))]
+        need = L.csim_netlist_csv_header(self._h, None, 0)
+        buf = C.create_string_buffer(need + 1)
+        L.csim_netlist_csv_header(self._h, buf, need + 1)
+        self.csv_header = buf.value.decode()
+        self.n_params = self._n_params()
+        self.nominal_params = np.zeros(self.n_params, dtype=np.float64)
+        capi.check(L.csim_netlist_nominal_params(self._h, self.nominal_params.ctypes.data))
+        self.mc_kinds = np.zeros(self.n_params, dtype=np.int32)
+        capi.check(L.csim_netlist_mc_kinds(self._h, self.mc_kinds.ctypes.data))
+
+    def _n_params(self):
+        # csim_ir: int32 n_unknowns, n_node_eq, n_branch_eq, n_elems, n_params, ...
+        ir = capi.lib().csim_netlist_ir(self._h)
+        return int(C.cast(ir, C.POINTER(C.c_int32))[4])
+
+    @classmethod
+    def from_file(cls, path):
+        h = C.c_void_p()
+        capi.check(capi.lib().csim_netlist_parse_file(str(path).encode(), C.byref(h)))
+        return cls(h, source=str(path))
+
+    @classmethod
+    def from_text(cls, text):
+        data = text.encode() if isinstance(text, str) else bytes(text)
+        h = C.c_void_p()
+        capi.check(capi.lib().csim_netlist_parse_text(data, len(data), C.byref(h)))
+        return cls(h, source="<memory>")
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def ir_ptr(self):
+        return C.c_void_p(capi.lib().csim_netlist_ir(self._h))
+
+    def node_eq(self, name):
+        return capi.lib().csim_netlist_node_eq(self._h, str(name).encode())
+
+    def num_steps(self, tstep=None, tstop=None):
+        return capi.lib().csim_tran_num_steps(self.tstep if tstep is None else tstep,
+                                              self.tstop if tstop is None else tstop)
+
+    def dc_sweeps(self):
+        L = capi.lib()
+        out = []
+        for i in range(L.csim_netlist_num_dc_sweeps(self._h)):
+            e, a, b, s = C.c_int32(), C.c_double(), C.c_double(), C.c_double()
+            capi.check(L.csim_netlist_dc_sweep(self._h, i, C.byref(e), C.byref(a), C.byref(b), C.byref(s)))
+            out.append((e.value, a.value, b.value, s.value))
+        return out
+
+    def mc_params_host(self, seed, sigma, b_first, B):
+        """Host mirror of the device generator: numpy [P][B] (slot-major)."""
+        out = np.zeros((self.n_params, B), dtype=np.float64)
+        capi.check(capi.lib().csim_mc_params_host(self._h, seed, sigma, b_first, B, out.ctypes.data))
+        return out
+
+    def nominal_table(self, B):
+        return np.repeat(self.nominal_params[:, None], B, axis=1).copy()
+
+    def __del__(self):
+        try:
+            if self._h:
+                capi.lib().csim_netlist_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Engine:
+    """One engine per (circuit, GPU).  Raises CsimError if no HIP device."""
+
+    def __init__(self, netlist, device=0):
+        self.netlist = netlist
+        self.device = int(device)
+        h = C.c_void_p()
+        capi.check(capi.lib().csim_engine_create(netlist.handle, self.device, C.byref(h)))
+        self._h = h
+        self.N = netlist.n_unknowns
+        self.P = netlist.n_params
+
+    @property
+    def tran_kernel(self):
+        return capi.lib().csim_engine_tran_kernel(self._h).decode()
+
+    def set_kernel(self, which):
+        capi.check(capi.lib().csim_engine_set_kernel(self._h, {"auto": 0, "general": 1, "scheduled": 2}[which]))
+
+    # -- device-pointer forms (torch tensors on cuda:<device>, slot-major) ----
+    def _dev(self):
+        return "cuda:%d" % self.device
+
+    def _stream(self):
+        torch = _torch()
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def upload_params(self, table):
+        """numpy [P][B] -> device tensor"""
+        torch = _torch()
+        t = torch.from_numpy(np.ascontiguousarray(table, dtype=np.float64)).to(self._dev())
+        assert t.shape[0] == self.P
+        return t
+
+    def mc_params(self, seed, sigma, b_first, B):
+        torch = _torch()
+        out = torch.empty((self.P, B), dtype=torch.float64, device=self._dev())
+        capi.check(capi.lib().csim_mc_params_dev(self._h, seed, sigma, b_first, B, out.data_ptr(), self._stream()))
+        return out
+
+    def dc(self, params):
+        """params: device [P][B] -> (x [N][B], iters [B] int32, status [B] int32-bits)"""
+        torch = _torch()
+        B = params.shape[1]
+        x = torch.empty((self.N, B), dtype=torch.float64, device=self._dev())
+        it = torch.zeros(B, dtype=torch.int32, device=self._dev())
+        st = torch.zeros(B, dtype=torch.int32, device=self._dev())
+        capi.check(capi.lib().csim_dc_batch_dev(self._h, params.data_ptr(), B, x.data_ptr(), it.data_ptr(),
+                                                st.data_ptr(), self._stream()))
+        return x, it, st
+
+    def tran(self, params, x, tstep, step_first, n_steps, iters, status, probes=None, out_stride=1,
+             wave=None, step_iters=None):
+        """Advance the batch by n_steps time steps in place (x, iters, status are updated)."""
+        B = params.shape[1]
+        n_probe = 0
+        pe = None
+        if wave is not None:
+            pe = (C.c_int32 * len(probes))(*probes)
+            n_probe = len(probes)
+        capi.check(capi.lib().csim_tran_batch_dev(
+            self._h, params.data_ptr(), B, float(tstep), int(step_first), int(n_steps), pe, n_probe,
+            int(out_stride), wave.data_ptr() if wave is not None else None, x.data_ptr(), iters.data_ptr(),
+            status.data_ptr(), step_iters.data_ptr() if step_iters is not None else None, self._stream()))
+
+    # -- host-pointer forms (numpy, instance-major as in SURVEY.md 8b) --------
+    def dc_host(self, params=None, B=1):
+        if params is not None:
+            params = np.ascontiguousarray(params, dtype=np.float64)
+            B = params.shape[0]
+        x = np.zeros((B, self.N))
+        it = np.zeros(B, dtype=np.int32)
+        st = np.zeros(B, dtype=np.uint32)
+        capi.check(capi.lib().csim_dc_batch(self._h, params.ctypes.data if params is not None else None, B,
+                                            x.ctypes.data, it.ctypes.data, st.ctypes.data))
+        return x, it, st
+
+    def tran_host(self, params=None, B=1, tstep=None, tstop=None, tstart=None, probes=None, out_stride=1):
+        nl = self.netlist
+        tstep = nl.tstep if tstep is None else tstep
+        tstop = nl.tstop if tstop is None else tstop
+        tstart = nl.tstart if tstart is None else tstart
+        if params is not None:
+            params = np.ascontiguousarray(params, dtype=np.float64)
+            B = params.shape[0]
+        wave = None
+        pe = None
+        n_probe = 0
+        if probes is not None:
+            n_probe = len(probes)
+            pe = (C.c_int32 * n_probe)(*probes)
+            rows = capi.lib().csim_tran_num_rows(tstep, tstop, tstart, out_stride)
+            wave = np.zeros((B, rows, n_probe))
+        xf = np.zeros((B, self.N))
+        it = np.zeros(B, dtype=np.int64)
+        st = np.zeros(B, dtype=np.uint32)
+        capi.check(capi.lib().csim_tran_batch(
+            self._h, params.ctypes.data if params is not None else None, B, tstep, tstop, tstart, pe, n_probe,
+            out_stride, wave.ctypes.data if wave is not None else None, xf.ctypes.data, it.ctypes.data,
+            st.ctypes.data))
+        return wave, xf, it, st
+
+    def close(self):
+        if self._h:
+            capi.lib().csim_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def lu_solve_batch(A, b, device=0):
+    """Batched Solver::solveLinearSystemLU on the GPU.  A [B][n][n], b [B][n] numpy."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    B, n = b.shape
+    x = np.zeros((B, n))
+    flags = np.zeros(B, dtype=np.uint32)
+    capi.check(capi.lib().csim_lu_solve_batch(device, n, B, A.ctypes.data, b.ctypes.data, x.ctypes.data,
+                                              flags.ctypes.data))
+    return x, flags
