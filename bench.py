@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- NR-iteration x instances / second of the batched transient solve.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted
+on): tests/dbmixer.sp transient, B = 4096 Monte-Carlo-perturbed instances per
+GPU (sigma = 5 %, seed 12345, instance 0 nominal), every
+instance started from its own DC operating point.  One bench "step" = one
+launch of the transient kernel that advances ALL instances of the rank by
+`--tsteps` backward-Euler time steps (tstep = 1e-13 s from the netlist), with
+parameters, state and counters resident in HBM.  Weak scaling: every GPU gets
+its own B instances (global instance index = rank*B + i), no data-path
+collective; the netlist is broadcast once and results are gathered once,
+outside the timed region.
+
+value = NR iterations summed over all instances of all ranks in the K timed
+steps / max-over-ranks wall time of those steps.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_iter(N):
+    """Dense system the reference materialises per NR iteration + x in/out."""
+    return 8 * (N * N + 3 * N)
+
+
+def cpu_baseline(nl, params_host, n_inst, tstep, n_tsteps):
+    """Oracle (CPU restatement, 1 thread) on a bounded sample of the same workload."""
+    from oracle import binding as orc
+    t0 = time.perf_counter()
+    iters = 0
+    for b in range(n_inst):
+        r = orc.tran(nl.ir_ptr, nl.n_unknowns, params_host, b, tstep, tstep * n_tsteps, want_rows=False)
+        iters += r["iters"]
+    dt = time.perf_counter() - t0
+    return iters, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--tsteps", type=int, default=200, help="time steps per bench step (launch)")
+    ap.add_argument("--netlist", default=os.path.join(HERE, "tests", "golden", "dbmixer.sp"))
+    ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--sigma", type=float, default=0.05)
+    ap.add_argument("--kernel", default="auto", choices=["auto", "general", "scheduled"])
+    ap.add_argument("--cpu-iters", type=float, default=1.2e6, help="approx. NR iterations of the CPU sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from circuitsimulator_amd import Engine, Netlist, shard
+
+    rank, local_rank, world = shard.dist_env()
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
+                  file=sys.stderr)
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the engine has no CPU path", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    shard.init_process_group("nccl")
+
+    # ---- netlist: rank 0 reads, RCCL broadcast, every rank parses ------------
+    t0 = time.perf_counter()
+    text = open(args.netlist).read() if rank == 0 else ""
+    text = shard.broadcast_netlist_text(text, src=0, device=dev)
+    torch.cuda.synchronize()
+    bcast_ms = (time.perf_counter() - t0) * 1e3
+    nl = Netlist.from_text(text)
+    eng = Engine(nl, local_rank)
+    if args.kernel != "auto":
+        eng.set_kernel(args.kernel)
+    N, B, S = nl.n_unknowns, args.batch, args.tsteps
+    tstep = nl.tstep
+
+    # ---- per-rank shard of the global batch, regenerated from (seed, b, slot)
+    params = eng.mc_params(args.seed, args.sigma, rank * B, B)
+    x, dc_it, status = eng.dc(params)
+    iters = torch.zeros(B, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+
+    step_idx = 0
+    for _ in range(args.warmup):
+        eng.tran(params, x, tstep, step_idx, S, iters, status)
+        step_idx += S
+    torch.cuda.synchronize()
+    shard.barrier()
+    torch.cuda.synchronize()
+
+    it_before = iters.clone()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t_start = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        eng.tran(params, x, tstep, step_idx, S, iters, status)
+        ev[k][1].record()
+        step_idx += S
+    torch.cuda.synchronize()
+    shard.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t_start
+
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    local_iters = int((iters - it_before).sum().item())
+    total_iters = shard.all_reduce_sum(float(local_iters), device=dev)
+    wall_max = shard.all_reduce_max(wall, device=dev)
+    n_bad = int((status & 0x27).ne(0).sum().item())           # non-finite / non-converged / tiny pivot / fallback
+    n_bad = int(shard.all_reduce_sum(float(n_bad), device=dev))
+
+    # ---- gather of node voltages (probes of the netlist: V(102), V(103)) -----
+    t0 = time.perf_counter()
+    probes = nl.probes if nl.probes else [0]
+    local_v = x[probes, :].contiguous()
+    all_v = shard.all_gather_instances(local_v, B * world, device=dev)
+    torch.cuda.synchronize()
+    gather_ms = (time.perf_counter() - t0) * 1e3
+
+    if rank == 0:
+        value = total_iters / wall_max
+        avg_kern_s = float(np.mean(kern_ms)) * 1e-3
+        iters_per_launch = local_iters / args.steps
+        abytes = algorithmic_bytes_per_iter(N)
+        achieved = iters_per_launch * abytes / avg_kern_s / 1e9
+        rec = {
+            "metric": "NR-iteration x instances / sec (transient)",
+            "value": value,
+            "unit": "NR-iter*inst/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "tests/dbmixer.sp transient (N=%d unknowns), batch=%d MC-perturbed instances per GPU "
+                            "(sigma=%g, seed=%d), %d time steps of %.3g s per bench step"
+                            % (N, B, args.sigma, args.seed, S, tstep),
+                "batch_per_gpu": B,
+                "time_steps_per_step": S,
+                "kernel": eng.tran_kernel,
+                "nr_iters_per_step": iters_per_launch,
+                "flagged_instances": n_bad,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_unit": abytes,
+                "kernel_avg_ms": avg_kern_s * 1e3,
+            },
+            "netlist_bcast_ms": bcast_ms,
+            "result_gather_ms": gather_ms,
+            "gathered_shape": list(all_v.shape),
+        }
+        if world == 1 and not args.no_cpu:
+            # CPU baseline: the oracle (port of the reference algorithm), 1 thread,
+            # on the first instances of the same parameter table
+            ph = params[:, :64].cpu().numpy()
+            s_cpu = min(S * args.steps, 2000)
+            est_per_inst = 10.0 * s_cpu
+            n_cpu = int(max(1, min(64, round(args.cpu_iters / est_per_inst))))
+            ci, cdt = cpu_baseline(nl, ph, n_cpu, tstep, s_cpu)
+            rec["cpu_baseline"] = {
+                "value": ci / cdt,
+                "unit": "NR-iter*inst/s",
+                "cores": 1,
+                "kind": "port",
+                "sample": "oracle/mna_oracle.c, instances 0..%d of the same table, %d time steps from the DC "
+                          "point (%d NR iterations, %.1f s, host has %d cores)"
+                          % (n_cpu - 1, s_cpu, ci, cdt, os.cpu_count() or 0),
+            }
+        print(json.dumps(rec))
+
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

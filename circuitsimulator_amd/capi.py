@@ -86,6 +86,15 @@ def lib():
                 "circuitsimulator_amd: %s is missing -- build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
                 "There is no fallback path." % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64
+        # (same SONAME as /opt/rocm's).  Importing torch first makes libcsim's
+        # NEEDED libamdhip64.so.7 resolve to that already-loaded copy, so
+        # device pointers and streams are shared; loading libcsim first would
+        # pull in a second runtime that cannot see the device.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)

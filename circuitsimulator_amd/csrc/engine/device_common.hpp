@@ -45,12 +45,18 @@ __host__ __device__ inline LdsLayout ldsLayout(int N, int LD, int nTerms, int P)
     l.P = l.T + nTerms;
     l.xs = l.P + P;
     l.xp = l.xs + N;
-    l.sc = l.xp + N;
-    l.total = l.sc + N;
+    l.sc = l.G;                 // norm scratch aliases the matrix (dead after the solve)
+    l.total = l.xp + N;
     return l;
 }
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+
+// The general kernels are the FAITHFUL path (planner, DC, fallback): keep every
+// multiply and add separately rounded, like the reference's x86-64 build,
+// instead of letting hipcc contract them into FMAs.  Measured on buffer.sp:
+// worst deviation from the oracle 6.7e-10 -> 4.9e-11 (of a 1e-9 A floor).
+#pragma clang fp contract(off)
 
 // one wavefront per workgroup: LDS traffic of the wave is ordered by issue, so
 // this is a wait on the LDS queue plus a scheduling fence (the s_barrier of a
@@ -255,9 +261,8 @@ __device__ __forceinline__ void assemble(const GenPlan& pl, const double* T, dou
 // into the elimination by carrying the RHS column (identical operation order
 // per row: multipliers are applied in ascending k).  Rows whose multiplier is
 // exactly zero are skipped: a - 0*b == a, so this is bit-identical while the
-// matrix is ~10 % dense.  Back substitution is column-oriented (lane i
-// updates y_i as each x_j becomes known, j descending); the reference sums
-// row-wise in ascending j, so the two differ by rounding only.
+// matrix is ~10 % dense.  Back substitution keeps the reference's row-wise,
+// ascending-j summation order.
 //
 // Returns the solution component of lane i (< N) and ORs CSIM_ST_LU_* flags.
 __device__ __forceinline__ double lu_solve_wave(double* Gm, int N, int LD, double eps, int lane, unsigned& flags)
@@ -273,10 +278,16 @@ __device__ __forceinline__ double lu_solve_wave(double* Gm, int N, int LD, doubl
         int piv = k;
         double maxAbs = akk;
         if (akk == akk) {       // a NaN diagonal keeps pivot = k in the reference
-            const double cand = (lane >= k && lane < N && av == av) ? av : -1.0;
-            maxAbs = wave_max(cand);
-            const unsigned long long hit = __ballot(cand == maxAbs);
-            piv = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
+            // solver.hpp:50-56 restricted to the rows that can win: a zero (or NaN)
+            // entry never satisfies "val > maxAbs", so only non-zero candidates
+            // below the diagonal are visited, in ascending row order
+            unsigned long long cand = __ballot(lane > k && lane < N && av > 0.0);
+            while (cand) {
+                const int i = __ffsll((long long)cand) - 1;
+                cand &= cand - 1;
+                const double v = read_lane(av, i);
+                if (v > maxAbs) { maxAbs = v; piv = i; }
+            }
         }
         if (maxAbs < eps) { failed = true; break; }
 
@@ -297,11 +308,13 @@ __device__ __forceinline__ double lu_solve_wave(double* Gm, int N, int LD, doubl
         // lane j holds the pivot row entry a(k,j), j in (k, N]
         const double rowv = (lane > k && lane <= N) ? Gm[k * LD + lane] : 0.0;
 
-        unsigned long long todo = __ballot(lane > k && lane < N && colv != 0.0);
+        const bool active = lane > k && lane < N && colv != 0.0;
+        const double fmine = active ? colv / pivv : 0.0;            // solver.hpp:71, row = lane
+        unsigned long long todo = __ballot(active);
         while (todo) {
             const int i = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
-            const double f = read_lane(colv, i) / pivv;             // solver.hpp:71
+            const double f = read_lane(fmine, i);
             if (lane > k && lane <= N) Gm[i * LD + lane] -= f * rowv;   // :74 (+ RHS)
         }
         wave_sync();
@@ -312,17 +325,27 @@ __device__ __forceinline__ double lu_solve_wave(double* Gm, int N, int LD, doubl
         return 0.0;
     }
 
-    // back substitution, solver.hpp:116-128
-    double y = (lane < N) ? Gm[lane * LD + N] : 0.0;
+    // back substitution, solver.hpp:116-128, in the reference's order: row i
+    // (descending) subtracts U(i,j)*x(j) for j ascending.  Lane j owns x(j) and
+    // forms its product; the ordered sum walks the non-zero products only
+    // (sum - 0 == sum), so the sparse rows cost ~3 steps each.
+    const double y = (lane < N) ? Gm[lane * LD + N] : 0.0;
     double xv = 0.0;
-    for (int j = N - 1; j >= 0; --j) {
-        const double d = read_lane(diag, j);
-        const double yj = read_lane(y, j);
-        double xj;
-        if (fabs(d) < eps) { xj = 0.0; flags |= CSIM_ST_LU_ZERO_DIAG; }
-        else xj = yj / d;
-        if (lane == j) xv = xj;
-        if (lane < j) y -= Gm[lane * LD + j] * xj;
+    for (int i = N - 1; i >= 0; --i) {
+        const double u = (lane > i && lane < N) ? Gm[i * LD + lane] : 0.0;
+        const double prod = u * xv;                                  // :119
+        unsigned long long todo = __ballot(lane > i && lane < N && prod != 0.0);
+        double sum = read_lane(y, i);                                // :117
+        while (todo) {
+            const int j = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            sum -= read_lane(prod, j);
+        }
+        const double d = read_lane(diag, i);                         // :121
+        double xi;
+        if (fabs(d) < eps) { xi = 0.0; flags |= CSIM_ST_LU_ZERO_DIAG; }   // :122-124
+        else xi = sum / d;                                           // :126
+        if (lane == i) xv = xi;
     }
     return xv;
 }
