@@ -114,6 +114,8 @@ def tran(ir, N, params, b, tstep, tstop, tstart=0.0, x0=None, want_rows=True, wa
     """-> dict(rows [n_rows][1+N] or None, x_final, iters, status, n_steps, step_iters)"""
     keep, ptr, stride = _col(params, b)
     ns = lib().oracle_tran_num_steps(tstep, tstop)
+    if ns < 0:
+        raise RuntimeError("oracle_tran: invalid .TRAN numbers (tstep and tstop must be > 0)")
     rows = np.zeros((ns + 1, N + 1)) if want_rows else None
     nrows = C.c_int64()
     its = C.c_int64()

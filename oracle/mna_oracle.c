@@ -499,6 +499,7 @@ int oracle_dc(const csim_ir* ir, const double* params, int64_t pstride,
 
 int64_t oracle_tran_num_steps(double tstep, double tstop)
 {
+    if (!(tstep > 0.0) || !(tstop > 0.0)) return -1;        /* rejected at tanalisis.cpp:94-97 */
     return (int64_t)(int)floor(tstop / tstep + 1e-12);      /* tanalisis.cpp:238 */
 }
 

@@ -1,0 +1,309 @@
+"""GPU parity: the HIP kernels behind the C-ABI against the CPU oracle on identical
+parameter tables, against the golden anchors, and -- at BASELINE.json's batch sizes --
+through size-independent properties (batch invariance, chunk invariance, shard invariance).
+
+Bar: NR-iteration counts and status words EQUAL (integer trajectory fingerprint); node
+voltages and branch currents within 1e-9 relative with an absolute floor of 1e-6 (V / A);
+see conftest.rel_err for why the floor is what it is.
+"""
+import numpy as np
+import pytest
+
+from conftest import has_gpu, netlist_path, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device: the engine has no CPU path")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def engines(torch_mod, buffer_nl, dbmixer_nl):
+    from circuitsimulator_amd import Engine
+    return {"buffer": (buffer_nl, Engine(buffer_nl, 0)), "dbmixer": (dbmixer_nl, Engine(dbmixer_nl, 0))}
+
+
+def _orc():
+    from oracle import binding
+    return binding
+
+
+def _run_tran(torch, eng, params, n_steps, tstep, probes=None, stride=1, want_step_iters=False, chunks=None):
+    """DC + n_steps through the device-pointer ABI. Returns dict of numpy results."""
+    B = params.shape[1]
+    x, dc_it, st = eng.dc(params)
+    x_dc = x.clone()
+    iters = torch.zeros(B, dtype=torch.int64, device=x.device)
+    wave = None
+    if probes is not None:
+        rows = n_steps // stride + 1
+        wave = torch.zeros((rows, len(probes), B), dtype=torch.float64, device=x.device)
+    si = torch.zeros((n_steps, B), dtype=torch.int32, device=x.device) if want_step_iters else None
+    done = 0
+    for n in (chunks or [n_steps]):
+        eng.tran(params, x, tstep, done, n, iters, st, probes=probes, out_stride=stride, wave=wave,
+                 step_iters=si[done:done + n] if si is not None else None)
+        done += n
+    assert done == n_steps
+    torch.cuda.synchronize()
+    return dict(x=x.cpu().numpy(), x_dc=x_dc.cpu().numpy(), dc_iters=dc_it.cpu().numpy(),
+                iters=iters.cpu().numpy(), status=st.cpu().numpy().astype(np.uint32),
+                wave=wave.cpu().numpy() if wave is not None else None,
+                step_iters=si.cpu().numpy() if si is not None else None)
+
+
+# ------------------------------------------------------------------ DC (K2)
+
+@pytest.mark.parametrize("name", ["buffer", "dbmixer"])
+def test_dc_nominal_vs_anchors_and_oracle(name, engines, anchors):
+    nl, eng = engines[name]
+    a = anchors[name]
+    x, it, st = eng.dc_host(B=3)
+    xo, ito, sto = _orc().dc(nl.ir_ptr, nl.n_unknowns, nl.nominal_params)
+    assert list(it) == [a["dc_iters"]] * 3 == [ito] * 3
+    assert list(st) == [sto] * 3
+    assert np.array_equal(x[0], x[1]) and np.array_equal(x[0], x[2])
+    assert rel_err(x[0], xo, nl.n_node_eq).max() < TOL
+    for eqname, s in a["dc_x"].items():           # golden 17-digit anchors
+        i = nl.eq_names.index(eqname)
+        floor = 1e-6
+        assert abs(x[0][i] - float(s)) <= TOL * max(abs(float(s)), floor), eqname
+
+
+@pytest.mark.parametrize("name", ["buffer", "dbmixer"])
+def test_dc_mc_batch_vs_oracle(name, engines, torch_mod):
+    nl, eng = engines[name]
+    B = 64
+    params = eng.mc_params(12345, 0.05, 0, B)
+    x, it, st = eng.dc(params)
+    torch_mod.cuda.synchronize()
+    ph = params.cpu().numpy()
+    x, it, st = x.cpu().numpy(), it.cpu().numpy(), st.cpu().numpy().astype(np.uint32)
+    for b in (0, 1, 2, 3, 17, B - 1):
+        xo, ito, sto = _orc().dc(nl.ir_ptr, nl.n_unknowns, ph, b)
+        assert it[b] == ito and st[b] == sto, (b, it[b], ito, st[b], sto)
+        assert rel_err(x[:, b], xo, nl.n_node_eq).max() < TOL, b
+
+
+def test_mc_params_device_equals_host_bitwise(engines, torch_mod):
+    nl, eng = engines["dbmixer"]
+    dev = eng.mc_params(12345, 0.05, 1000, 513).cpu().numpy()
+    host = nl.mc_params_host(12345, 0.05, 1000, 513)
+    assert np.array_equal(dev, host)
+    assert np.array_equal(eng.mc_params(12345, 0.05, 0, 4).cpu().numpy()[:, 0], nl.nominal_params)
+
+
+# ----------------------------------------------------------- transient (K1)
+
+def test_buffer_transient_as_shipped_full_waveform(engines, torch_mod, anchors):
+    nl, eng = engines["buffer"]
+    params = eng.upload_params(nl.nominal_table(2))
+    r = _run_tran(torch_mod, eng, params, 300, nl.tstep, probes=list(range(nl.n_unknowns)), want_step_iters=True)
+    o = _orc().tran(nl.ir_ptr, nl.n_unknowns, nl.nominal_params, 0, nl.tstep, nl.tstop, want_step_iters=True)
+    assert r["iters"][0] == anchors["buffer"]["tran_iters"] == o["iters"]
+    assert np.array_equal(r["step_iters"][:, 0], o["step_iters"])
+    assert r["status"][0] == o["status"]
+    wave = np.transpose(r["wave"], (2, 0, 1))          # [B][rows][N]
+    assert np.array_equal(wave[0], wave[1])
+    assert rel_err(wave[0], o["rows"][:, 1:], nl.n_node_eq).max() < TOL
+    for eqname, s in anchors["buffer"]["last_row"].items():
+        i = nl.eq_names.index(eqname)
+        floor = 1e-6
+        assert abs(wave[0][-1][i] - float(s)) <= TOL * max(abs(float(s)), floor)
+
+
+def test_buffer_10k_steps_batch1_config(engines, torch_mod, anchors):
+    """BASELINE.json configs[1]: buffer.sp transient 10 000 steps, batch = 1 (.TRAN 3e-11 300e-9)."""
+    nl, eng = engines["buffer"]
+    tstep, tstop = 3e-11, 300e-9
+    assert nl.num_steps(tstep, tstop) == 10000
+    params = eng.upload_params(nl.nominal_table(1))
+    r = _run_tran(torch_mod, eng, params, 10000, tstep, probes=list(range(nl.n_unknowns)), stride=1,
+                  want_step_iters=True, chunks=[4096, 4096, 1808])
+    o = _orc().tran(nl.ir_ptr, nl.n_unknowns, nl.nominal_params, 0, tstep, tstop, want_step_iters=True)
+    assert r["iters"][0] == anchors["buffer"]["tran10k_iters"] == o["iters"]
+    assert np.array_equal(r["step_iters"][:, 0], o["step_iters"])
+    assert rel_err(r["wave"][:, :, 0], o["rows"][:, 1:], nl.n_node_eq).max() < TOL
+
+
+def test_dbmixer_mc_transient_vs_oracle(engines, torch_mod):
+    nl, eng = engines["dbmixer"]
+    B, steps = 64, 1500
+    params = eng.mc_params(12345, 0.05, 0, B)
+    r = _run_tran(torch_mod, eng, params, steps, nl.tstep, probes=nl.probes, stride=100, want_step_iters=True)
+    ph = params.cpu().numpy()
+    for b in (0, 1, 2, 3, B - 1):
+        o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstep * steps, want_step_iters=True)
+        assert r["iters"][b] == o["iters"], b
+        assert np.array_equal(r["step_iters"][:, b], o["step_iters"]), b
+        assert r["status"][b] == o["status"], b
+        assert rel_err(r["x"][:, b], o["x_final"], nl.n_node_eq).max() < TOL, b
+        ref = o["rows"][::100, 1:][:, nl.probes]
+        assert np.abs(r["wave"][:, :, b] - ref).max() <= TOL * np.abs(ref).max()
+
+
+def test_dbmixer_full_run_nominal(engines, torch_mod, anchors):
+    """tests/dbmixer.sp as shipped: 50 000 steps; totals and every row against the oracle."""
+    nl, eng = engines["dbmixer"]
+    a = anchors["dbmixer"]
+    wave, xf, it, st = eng.tran_host(B=1, probes=list(range(nl.n_unknowns)))
+    assert it[0] == a["tran_iters"] and st[0] == 0
+    o = _orc().tran(nl.ir_ptr, nl.n_unknowns, nl.nominal_params, 0, nl.tstep, nl.tstop)
+    assert wave.shape == (1, 50001, 31)
+    assert rel_err(wave[0], o["rows"][:, 1:], nl.n_node_eq).max() < TOL
+    for eqname, s in a["last_row"].items():
+        i = nl.eq_names.index(eqname)
+        floor = 1e-6
+        assert abs(xf[0][i] - float(s)) <= TOL * max(abs(float(s)), floor)
+
+
+# ------------------------------------- full-size, size-independent properties
+
+def test_batch4096_invariances(engines, torch_mod):
+    """BASELINE.json configs[2] size (dbmixer, B = 4096): results of an instance do not depend
+    on the batch it is in, on how the time axis is chunked into launches, or on the shard."""
+    torch = torch_mod
+    nl, eng = engines["dbmixer"]
+    B, steps = 4096, 60
+    params = eng.mc_params(12345, 0.05, 0, B)
+    # make column 7 a duplicate of column 4000: equal inputs -> bitwise equal outputs
+    params[:, 7] = params[:, 4000]
+    whole = _run_tran(torch, eng, params, steps, nl.tstep)
+    assert not (whole["status"] & 0x27).any()
+    assert np.array_equal(whole["x"][:, 7], whole["x"][:, 4000]) and whole["iters"][7] == whole["iters"][4000]
+    # chunked time axis == single launch, bitwise
+    chunked = _run_tran(torch, eng, params, steps, nl.tstep, chunks=[1, 29, 30])
+    assert np.array_equal(chunked["x"], whole["x"]) and np.array_equal(chunked["iters"], whole["iters"])
+    # two shards (as two ranks would run them) == whole batch, bitwise
+    lo = _run_tran(torch, eng, params[:, :2048].contiguous(), steps, nl.tstep)
+    hi = _run_tran(torch, eng, params[:, 2048:].contiguous(), steps, nl.tstep)
+    assert np.array_equal(np.concatenate([lo["x"], hi["x"]], axis=1), whole["x"])
+    assert np.array_equal(np.concatenate([lo["iters"], hi["iters"]]), whole["iters"])
+    # instance 0 is the nominal circuit: equals a batch-of-one run of the netlist
+    one = _run_tran(torch, eng, eng.upload_params(nl.nominal_table(1)), steps, nl.tstep)
+    assert np.array_equal(one["x"][:, 0], whole["x"][:, 0]) and one["iters"][0] == whole["iters"][0]
+    # spot-check against the oracle at this size
+    ph = params[:, [0, 1, 4095]].cpu().numpy()
+    for j, b in enumerate((0, 1, 4095)):
+        o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, j, nl.tstep, nl.tstep * steps, want_rows=False)
+        assert whole["iters"][b] == o["iters"]
+        assert rel_err(whole["x"][:, b], o["x_final"], nl.n_node_eq).max() < TOL
+
+
+# ------------------------------------------------ host-pointer API, edge cases
+
+def test_host_api_tstart_and_stride(engines):
+    nl, eng = engines["buffer"]
+    wave, xf, it, st = eng.tran_host(B=2, tstep=1e-9, tstop=20e-9, tstart=5e-9, probes=[1, 8], out_stride=2)
+    o = _orc().tran(nl.ir_ptr, nl.n_unknowns, nl.nominal_params, 0, 1e-9, 20e-9)
+    keep = [r for r in range(0, 21, 2) if (0.0 if r == 0 else r * 1e-9) >= 5e-9]
+    assert wave.shape == (2, len(keep), 2)
+    ref = o["rows"][keep][:, [2, 9]]
+    assert np.abs(wave[0] - ref).max() <= TOL * np.abs(ref).max()
+    assert it[0] == o["iters"]
+
+
+def test_host_api_instance_major_params(engines):
+    nl, eng = engines["dbmixer"]
+    tab = nl.mc_params_host(12345, 0.05, 0, 5)             # [P][B]
+    x, it, st = eng.dc_host(np.ascontiguousarray(tab.T))   # [B][P]
+    for b in range(5):
+        xo, ito, sto = _orc().dc(nl.ir_ptr, nl.n_unknowns, tab, b)
+        assert it[b] == ito and st[b] == sto
+        assert rel_err(x[b], xo, nl.n_node_eq).max() < TOL
+
+
+def test_error_codes(engines):
+    from circuitsimulator_amd import capi, CsimError, Engine, Netlist
+    nl, eng = engines["buffer"]
+    with pytest.raises(CsimError) as e:
+        eng.tran_host(B=1, tstep=0.0, tstop=1e-9)
+    assert e.value.code == capi.CSIM_ERR_CONFIG          # tanalisis.cpp:94-97
+    with pytest.raises(CsimError) as e:
+        Engine(Netlist.from_text("* empty\n"), 0)
+    assert e.value.code == capi.CSIM_ERR_EMPTY           # tanalisis.cpp:103-107
+    with pytest.raises(CsimError) as e:
+        Engine(nl, 99)
+    assert e.value.code == capi.CSIM_ERR_NO_DEVICE
+    big = "V1 n0 0 1\n" + "".join("R%d n%d n%d 1\n" % (i, i, i + 1) for i in range(70)) + "R99 n70 0 1\n"
+    with pytest.raises(CsimError) as e:
+        Engine(Netlist.from_text(big), 0)
+    assert e.value.code == capi.CSIM_ERR_UNSUPPORTED
+    x, it, st = eng.dc_host(np.zeros((0, nl.n_params)))  # empty batch is a no-op
+    assert x.shape == (0, nl.n_unknowns)
+
+
+def test_linear_circuit_direct_dc_and_rc_transient(torch_mod):
+    """Linear circuits take the direct DC path: one solve, no gmin (dcanalysis.cpp:46-68)."""
+    from circuitsimulator_amd import Engine, Netlist
+    text = ("V1 n1 0 SIN 0 1 1e6 0\n" + "".join("R%d n%d n%d 100\n" % (k, k, k + 1) for k in range(1, 12)) +
+            "".join("C%d n%d 0 1e-12\n" % (k, k) for k in range(2, 13)) + ".TRAN 1e-9 100e-9\n")
+    nl = Netlist.from_text(text)
+    eng = Engine(nl, 0)
+    x, it, st = eng.dc_host(B=2)
+    xo, ito, sto = _orc().dc(nl.ir_ptr, nl.n_unknowns, nl.nominal_params)
+    assert it[0] == ito == 1 and st[0] == sto
+    assert rel_err(x[0], xo, nl.n_node_eq).max() < TOL
+    wave, xf, itr, stt = eng.tran_host(B=2, probes=list(range(nl.n_unknowns)))
+    o = _orc().tran(nl.ir_ptr, nl.n_unknowns, nl.nominal_params, 0, nl.tstep, nl.tstop)
+    assert itr[0] == o["iters"] and stt[0] == o["status"]
+    assert rel_err(wave[0], o["rows"][:, 1:], nl.n_node_eq).max() < TOL
+
+
+def test_floating_node_gives_zero_vector_and_flag(torch_mod):
+    from circuitsimulator_amd import Engine, Netlist
+    nl = Netlist.from_text("V1 a 0 1\nR1 a 0 1k\nC1 b 0 1p\n")
+    x, it, st = Engine(nl, 0).dc_host(B=1)
+    assert it[0] == 1 and (st[0] & 0x4) and np.array_equal(x[0], np.zeros(3))
+
+
+# ------------------------------------------------------- batched LU (a1, a2)
+
+def test_lu_known_answers():
+    from circuitsimulator_amd import lu_solve_batch
+    A = np.array([[[0.0, 2.0], [3.0, 1.0]],          # forced row swap
+                  [[1.0, 2.0], [2.0, 4.0]],          # singular: second pivot exactly 0 -> zero vector
+                  [[1e-16, 0.0], [0.0, 1.0]],        # column maximum below 1e-15 -> zero vector
+                  [[2.0, 0.0], [0.0, 4.0]]])
+    b = np.array([[4.0, 5.0], [1.0, 1.0], [1.0, 1.0], [2.0, 2.0]])
+    x, flags = lu_solve_batch(A, b)
+    assert np.allclose(x[0], [1.0, 2.0], rtol=0, atol=1e-15) and flags[0] == 0
+    assert np.array_equal(x[1], [0.0, 0.0]) and flags[1] & 0x4
+    assert np.array_equal(x[2], [0.0, 0.0]) and flags[2] & 0x4
+    assert np.array_equal(x[3], [1.0, 0.5]) and flags[3] == 0
+
+
+def test_lu_random_systems_bitwise_equal_to_oracle():
+    """Same pivot rule, same operation order, no FMA contraction -> the same bits."""
+    from circuitsimulator_amd import lu_solve_batch
+    rs = np.random.RandomState(3)
+    for n in (1, 2, 5, 13, 31, 47, 63):
+        B = 9
+        A = rs.randn(B, n, n)
+        A[rs.rand(B, n, n) < 0.6] = 0.0                 # sparse like an MNA matrix
+        A += np.eye(n)[None] * rs.choice([1.0, 1e-3, 5.0], size=(B, n))[:, :, None]
+        A[0, 0, :] = 0.0; A[0, 0, n - 1] = 1.0           # make pivoting happen
+        b = rs.randn(B, n)
+        x, flags = lu_solve_batch(A, b)
+        for i in range(B):
+            xo, fo = _orc().solve_lu(A[i], b[i])
+            assert flags[i] == fo
+            assert np.array_equal(x[i], xo), (n, i, np.abs(x[i] - xo).max())
+
+
+def test_lu_pivot_tie_takes_first_row():
+    from circuitsimulator_amd import lu_solve_batch
+    A = np.array([[[1.0, 2.0, 3.0], [-1.0, 1.0, 0.0], [1.0, 0.0, 5.0]],
+                  [[0.5, 2.0, 3.0], [-1.0, 1.0, 0.0], [1.0, 0.0, 5.0]]])
+    b = np.array([[1.0, 2.0, 3.0], [1.0, 2.0, 3.0]])
+    x, flags = lu_solve_batch(A, b)
+    for i in range(2):
+        xo, fo = _orc().solve_lu(A[i], b[i])
+        assert np.array_equal(x[i], xo) and flags[i] == fo
