@@ -1,0 +1,595 @@
+// codegen.cpp -- see codegen.hpp.  Symbolic execution of stamp + pivoted LU +
+// substitution over {zero, exact constant, run-time value}; emits HIP source.
+#include "codegen.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+
+namespace csim {
+
+// ------------------------------------------------------------ schedule utils
+
+PivotSchedule PivotSchedule::identity(int N)
+{
+    PivotSchedule s;
+    s.pivotPos.resize(static_cast<std::size_t>(N));
+    for (int k = 0; k < N; ++k) s.pivotPos[static_cast<std::size_t>(k)] = k;
+    return s;
+}
+
+bool PivotSchedule::parse(const std::string& text, int N, PivotSchedule& out)
+{
+    out = identity(N);
+    std::size_t i = 0;
+    while (i < text.size()) {
+        while (i < text.size() && (text[i] == ',' || text[i] == ' ' || text[i] == '\n' || text[i] == '\t')) ++i;
+        if (i >= text.size()) break;
+        int k = 0, p = 0, used = 0;
+        if (std::sscanf(text.c_str() + i, "%d:%d%n", &k, &p, &used) != 2) return false;
+        if (k < 0 || k >= N || p < k || p >= N) return false;
+        out.pivotPos[static_cast<std::size_t>(k)] = p;
+        i += static_cast<std::size_t>(used);
+    }
+    return true;
+}
+
+std::string PivotSchedule::str() const
+{
+    std::ostringstream o;
+    bool first = true;
+    for (std::size_t k = 0; k < pivotPos.size(); ++k) {
+        if (pivotPos[k] == static_cast<int>(k)) continue;
+        o << (first ? "" : ",") << k << ":" << pivotPos[k];
+        first = false;
+    }
+    return o.str();
+}
+
+uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch)
+{
+    uint64_t h = 1469598103934665603ull;                 // FNV-1a
+    auto mixBytes = [&h](const void* p, std::size_t n) {
+        const unsigned char* b = static_cast<const unsigned char*>(p);
+        for (std::size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    };
+    auto mixInt = [&](int32_t v) { mixBytes(&v, sizeof v); };
+    mixInt(2);                                            // generator revision
+    mixInt(ir.n_unknowns); mixInt(ir.n_node_eq); mixInt(ir.n_branch_eq);
+    mixInt(ir.n_elems); mixInt(ir.n_params); mixInt(ir.has_nonlinear);
+    for (int e = 0; e < ir.n_elems; ++e) {
+        mixInt(ir.kind[e]);
+        for (int t = 0; t < 4; ++t) mixInt(ir.eq[4 * e + t]);
+        mixInt(ir.branch_eq[e]); mixInt(ir.param_slot[e]); mixInt(ir.wave[e]);
+    }
+    mixBytes(&ir.k, sizeof ir.k);
+    for (int p : sch.pivotPos) mixInt(p);
+    return h;
+}
+
+// ------------------------------------------------------------ abstract values
+
+namespace {
+
+struct AV {
+    enum Kind { ZERO, CONST, DYN } kind = ZERO;
+    double c = 0.0;          // CONST
+    std::string v;           // DYN: variable name
+    bool neg = false;        // DYN: value is -(v)
+    static AV zero() { return AV(); }
+    static AV konst(double x) { AV a; if (x == 0.0) return a; a.kind = CONST; a.c = x; return a; }
+    static AV dyn(const std::string& name, bool n = false) { AV a; a.kind = DYN; a.v = name; a.neg = n; return a; }
+    bool isZero() const { return kind == ZERO; }
+};
+
+std::string lit(double x)
+{
+    char buf[64];
+    std::snprintf(buf, sizeof buf, "%a", x);
+    return std::string("(") + buf + ")";
+}
+
+struct Gen {
+    const csim_ir& ir;
+    const AssemblyPlan& ap;
+    std::ostringstream out;
+    // deferred entries: ordered term lists not yet turned into code (lazy assembly keeps
+    // an entry out of the register file until the elimination first touches it)
+    std::vector<std::vector<std::vector<AV>>> pending;
+    int tmp = 0;
+    CodegenStats st;
+    std::string ind = "            ";
+
+    Gen(const csim_ir& i, const AssemblyPlan& a) : ir(i), ap(a) {}
+
+    std::string fresh() { return "v" + std::to_string(tmp++); }
+    std::string ref(const AV& a) const
+    {
+        if (a.kind == AV::CONST) return lit(a.c);
+        if (a.kind == AV::DYN) return a.neg ? "(-" + a.v + ")" : a.v;
+        return "0.0";
+    }
+    AV emit(const std::string& expr)
+    {
+        const std::string n = fresh();
+        out << ind << "const double " << n << " = " << expr << ";\n";
+        return AV::dyn(n);
+    }
+    AV negate(AV a)
+    {
+        if (a.kind == AV::CONST) a.c = -a.c;
+        else if (a.kind == AV::DYN) a.neg = !a.neg;
+        return a;
+    }
+    // a * b
+    AV mul(const AV& a, const AV& b)
+    {
+        if (a.isZero() || b.isZero()) return AV::zero();
+        if (a.kind == AV::CONST && b.kind == AV::CONST) return AV::konst(a.c * b.c);
+        if (a.kind == AV::CONST || b.kind == AV::CONST) {
+            const AV& k = a.kind == AV::CONST ? a : b;
+            const AV& d = a.kind == AV::CONST ? b : a;
+            if (k.c == 1.0) return d;
+            if (k.c == -1.0) return negate(d);
+            ++st.nMul;
+            return emit(lit(k.c) + " * " + ref(d));
+        }
+        ++st.nMul;
+        AV r = emit(a.v + " * " + b.v);
+        r.neg = a.neg != b.neg;
+        return r;
+    }
+    // a - f*u
+    AV fnma(const AV& a, const AV& f, const AV& u)
+    {
+        if (f.isZero() || u.isZero()) return a;
+        if (a.isZero()) return negate(mul(f, u));
+        // fold exact +-1 factors into an add/sub
+        const bool f1 = f.kind == AV::CONST && std::fabs(f.c) == 1.0;
+        const bool u1 = u.kind == AV::CONST && std::fabs(u.c) == 1.0;
+        if (f.kind == AV::CONST && u.kind == AV::CONST) {
+            const double p = f.c * u.c;
+            if (a.kind == AV::CONST) return AV::konst(a.c - p);
+            ++st.nAddSub;
+            return emit(ref(a) + " - " + lit(p));
+        }
+        if (f1 || u1) {
+            AV w = f1 ? u : f;
+            const double s = f1 ? f.c : u.c;
+            if (s < 0) w = negate(w);
+            ++st.nAddSub;
+            return emit(ref(a) + " - " + ref(w));
+        }
+        ++st.nFma;
+        return emit(ref(a) + " - " + ref(f) + " * " + ref(u));
+    }
+    // ordered sum of signed terms (the reference's accumulation order)
+    AV orderedSum(const std::vector<AV>& terms)
+    {
+        bool allConst = true;
+        for (const AV& t : terms) allConst = allConst && t.kind != AV::DYN;
+        if (allConst) {
+            double acc = 0.0;
+            for (const AV& t : terms) acc = acc + (t.kind == AV::CONST ? t.c : 0.0);
+            return AV::konst(acc);
+        }
+        std::vector<AV> nz;
+        for (const AV& t : terms) if (!t.isZero()) nz.push_back(t);
+        if (nz.size() == 1) return nz[0];
+        std::string e;
+        for (std::size_t i = 0; i < nz.size(); ++i) {
+            const AV& t = nz[i];
+            if (i == 0) { e = ref(t); continue; }
+            if (t.kind == AV::DYN) e = "(" + e + (t.neg ? " - " : " + ") + t.v + ")";
+            else e = "(" + e + " + " + lit(t.c) + ")";
+            ++st.nAddSub;
+        }
+        return emit(e);
+    }
+};
+
+// the iterate x lives in LDS, one private column per lane: X(i) = lds[i*64 + lane]
+std::string xname(int eq) { return eq >= 0 ? "X(" + std::to_string(eq) + ")" : std::string("0.0"); }
+// register copy of x(eq) made at the top of an iteration
+std::string xloc(int eq) { return eq >= 0 ? "xl" + std::to_string(eq) : std::string("0.0"); }
+std::string pname(int slot) { return "p" + std::to_string(slot); }
+std::string tname(int t) { return "t" + std::to_string(t); }
+
+// difference of two node voltages as an expression
+std::string vdiff(int a, int b)
+{
+    if (a < 0 && b < 0) return "0.0";
+    if (b < 0) return xname(a);
+    if (a < 0) return "(-" + xname(b) + ")";
+    return "(" + xname(a) + " - " + xname(b) + ")";
+}
+
+} // namespace
+
+// ------------------------------------------------------------------ generator
+
+std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch,
+                                     const std::string& label, CodegenStats* statsOut)
+{
+    const int N = ir.n_unknowns;
+    const int LD = ap.LD;
+    const csim_consts& K = ir.k;
+    const uint64_t hash = scheduleHash(ir, sch);
+    Gen g(ir, ap);
+
+    // term -> abstract value.  Exact constants: the global ONE term and the
+    // inductor incidence "one" (precondition L > 0 is checked per instance).
+    std::vector<AV> termAV(static_cast<std::size_t>(ap.nTerms));
+    for (int t = 0; t < ap.nTerms; ++t) termAV[static_cast<std::size_t>(t)] = AV::dyn(tname(t));
+    termAV[static_cast<std::size_t>(ap.termOne)] = AV::konst(1.0);
+    for (int e = 0; e < ir.n_elems; ++e)
+        if (ir.kind[e] == CSIM_L)
+            termAV[static_cast<std::size_t>(ap.termBase[static_cast<std::size_t>(e)] + T_L_ONE)] = AV::konst(1.0);
+
+    // terms that do not change inside the Newton loop (launch- or step-constant)
+    std::vector<char> invariant(static_cast<std::size_t>(ap.nTerms), 1);
+    for (int e = 0; e < ir.n_elems; ++e)
+        if (ir.kind[e] == CSIM_NMOS || ir.kind[e] == CSIM_PMOS)
+            for (int o = T_M_GD; o <= T_M_CST; ++o)
+                invariant[static_cast<std::size_t>(ap.termBase[static_cast<std::size_t>(e)] + o)] = 0;
+
+    std::ostringstream src;
+    src << "// GENERATED by circuitsimulator_amd/csrc/engine/codegen.cpp -- do not edit.\n"
+        << "// circuit: " << label << "   N=" << N << "  elements=" << ir.n_elems << "  P=" << ir.n_params << "\n"
+        << "// pivot schedule (column:row position): " << (sch.str().empty() ? "identity" : sch.str()) << "\n"
+        << "// One lane = one circuit instance; see codegen.hpp for what is and is not\n"
+        << "// identical to the reference arithmetic.\n"
+        << "#include <hip/hip_runtime.h>\n#include <stdint.h>\n\n"
+        << "#define ST_TRAN_NONFINITE 0x0001u\n#define ST_TRAN_NONCONV 0x0002u\n\n";
+
+    // ---- which terms are per-step (sources, history currents): they live in LDS too
+    std::vector<int> stepSlot(static_cast<std::size_t>(ap.nTerms), -1);
+    int nStep = 0;
+    for (int e = 0; e < ir.n_elems; ++e) {
+        const int tb = ap.termBase[static_cast<std::size_t>(e)];
+        switch (ir.kind[e]) {
+            case CSIM_V: case CSIM_I: stepSlot[static_cast<std::size_t>(tb + T_SRC_VAL)] = nStep++; break;
+            case CSIM_C: stepSlot[static_cast<std::size_t>(tb + T_C_IH)] = nStep++; break;
+            case CSIM_L: stepSlot[static_cast<std::size_t>(tb + T_L_VH)] = nStep++; break;
+            case CSIM_NMOS: case CSIM_PMOS:
+                for (int o = T_M_IHGS; o <= T_M_IHDB; ++o) stepSlot[static_cast<std::size_t>(tb + o)] = nStep++;
+                break;
+            default: break;
+        }
+    }
+    auto sname = [&](int t) { return "S(" + std::to_string(stepSlot[static_cast<std::size_t>(t)]) + ")"; };
+    for (int t = 0; t < ap.nTerms; ++t)
+        if (stepSlot[static_cast<std::size_t>(t)] >= 0) termAV[static_cast<std::size_t>(t)] = AV::dyn(sname(t));
+
+    // LDS layout: lds[slot*64 + lane]; slots 0..N-1 = x, N.. = per-step terms.  Every
+    // lane only ever touches its own column, so no barrier or fence is needed.
+    src << "#define X(i) lds[(i) * 64 + lane]\n#define S(j) lds[(" << N << " + (j)) * 64 + lane]\n\n"
+        << "// Newton-refined reciprocal (v_rcp_f64 + 2 FMA pairs, ~1 ulp) for the pivots\n"
+        << "__device__ __forceinline__ double rcp_nr(double a)\n{\n"
+        << "    double r = __builtin_amdgcn_rcp(a);\n"
+        << "    r = fma(fma(-a, r, 1.0), r, r);\n"
+        << "    r = fma(fma(-a, r, 1.0), r, r);\n"
+        << "    return r;\n}\n\n";
+
+    src << "extern \"C\" __global__ void __launch_bounds__(64)\n"
+        << "csim_tran_sched_kernel(const double* __restrict__ params, int B, double dt, long long stepFirst,\n"
+        << "                       long long nSteps, const int* __restrict__ probeEq, int nProbe, int outStride,\n"
+        << "                       double* __restrict__ wave, double* __restrict__ xio, long long* __restrict__ iters,\n"
+        << "                       unsigned* __restrict__ status, int* __restrict__ stepIters,\n"
+        << "                       unsigned char* __restrict__ fallback)\n{\n"
+        << "    __shared__ double lds[" << (N + nStep) << " * 64];\n"
+        << "    const int lane = threadIdx.x;\n"
+        << "    const int b = blockIdx.x * 64 + threadIdx.x;\n"
+        << "    const bool inb = b < B;\n"
+        << "    const long long bb = inb ? b : B - 1;      // out-of-range lanes shadow the last instance, never store\n"
+        << "    const long long SB = B;\n";
+
+    // ---- parameters
+    for (int p = 0; p < ir.n_params; ++p)
+        src << "    const double " << pname(p) << " = params[" << p << "LL * SB + bb];\n";
+
+    // ---- launch-constant terms (device_common.hpp terms_const<true>)
+    src << "    bool viol = false;      // pivot schedule (or a precondition of it) violated -> general kernel\n";
+    for (int e = 0; e < ir.n_elems; ++e) {
+        const int s = ir.param_slot[e], tb = ap.termBase[static_cast<std::size_t>(e)];
+        switch (ir.kind[e]) {
+            case CSIM_R:
+                src << "    const double " << tname(tb + T_R_G) << " = (" << pname(s) << " == 0.0) ? 0.0 : 1.0 / " << pname(s) << ";\n";
+                break;
+            case CSIM_C:
+                src << "    const double " << tname(tb + T_C_GC) << " = (" << pname(s) << " > 0.0 && dt > 0.0) ? " << pname(s) << " / dt : 0.0;\n";
+                break;
+            case CSIM_L:
+                src << "    const double " << tname(tb + T_L_REQ) << " = " << pname(s) << " / dt;\n"
+                    << "    viol = viol || !(" << pname(s) << " > 0.0);   // incidence +-1 folded as constants\n";
+                break;
+            case CSIM_NMOS: case CSIM_PMOS:
+                src << "    const double ch" << e << " = 0.5 * " << pname(s + 3) << ";\n"
+                    << "    const double " << tname(tb + T_M_GCH) << " = (ch" << e << " > 0.0 && dt > 0.0) ? ch" << e << " / dt : 0.0;\n"
+                    << "    const double " << tname(tb + T_M_GCF) << " = (" << pname(s + 3) << " > 0.0 && dt > 0.0) ? " << pname(s + 3) << " / dt : 0.0;\n";
+                break;
+            default: break;
+        }
+    }
+    src << "    const double " << tname(ap.termGmin) << " = " << lit(K.tran_gmin) << ";\n";
+
+    // ---- state
+    for (int i = 0; i < N; ++i) src << "    X(" << i << ") = xio[" << i << "LL * SB + bb];\n";
+    src << "    unsigned st = inb ? status[bb] : 0u;\n"
+        << "    bool dead = !inb || (st & ST_TRAN_NONFINITE) != 0u;   // the reference would have thrown: stay stopped\n"
+        << "    long long itTotal = 0;\n"
+        << "    if (stepFirst == 0 && wave && inb) {\n"
+        << "        for (int q = 0; q < nProbe; ++q) wave[((long long)q) * SB + b] = X(probeEq[q]);\n"
+        << "    }\n\n"
+        << "    for (long long s = 1; s <= nSteps; ++s) {\n"
+        << "        if (!__any(!dead && !viol)) break;\n"
+        << "        const long long gstep = stepFirst + s;\n"
+        << "        const double tNow = (double)(int)gstep * dt;\n";
+
+    // ---- per-step terms (device_common.hpp terms_step_tran), stored to LDS
+    const std::string i2 = "        ";
+    for (int e = 0; e < ir.n_elems; ++e) {
+        const int s = ir.param_slot[e], tb = ap.termBase[static_cast<std::size_t>(e)];
+        const int32_t* q = ir.eq + 4 * e;
+        switch (ir.kind[e]) {
+            case CSIM_V: case CSIM_I:
+                if (ir.wave[e] == CSIM_WAVE_SIN) {
+                    src << i2 << "if (tNow < " << pname(s + 4) << ") " << sname(tb) << " = " << pname(s) << " + " << pname(s + 1) << ";\n"
+                        << i2 << "else " << sname(tb) << " = " << pname(s) << " + (" << pname(s + 1) << " + " << pname(s + 2)
+                        << " * sin((2.0 * " << lit(K.pi) << " * " << pname(s + 3) << ") * (tNow - " << pname(s + 4) << ") + "
+                        << pname(s + 5) << "));\n";
+                } else {
+                    src << i2 << sname(tb) << " = " << pname(s) << " + 0.0;\n";
+                }
+                break;
+            case CSIM_C:
+                src << i2 << sname(tb + T_C_IH) << " = -" << tname(tb + T_C_GC) << " * " << vdiff(q[0], q[1]) << ";\n";
+                break;
+            case CSIM_L:
+                src << i2 << sname(tb + T_L_VH) << " = -" << tname(tb + T_L_REQ) << " * X(" << ir.branch_eq[e] << ");\n";
+                break;
+            case CSIM_NMOS: case CSIM_PMOS:
+                src << i2 << sname(tb + T_M_IHGS) << " = -" << tname(tb + T_M_GCH) << " * " << vdiff(q[1], q[2]) << ";\n"
+                    << i2 << sname(tb + T_M_IHGD) << " = -" << tname(tb + T_M_GCH) << " * " << vdiff(q[1], q[0]) << ";\n"
+                    << i2 << sname(tb + T_M_IHSB) << " = -" << tname(tb + T_M_GCF) << " * " << vdiff(q[2], q[3]) << ";\n"
+                    << i2 << sname(tb + T_M_IHDB) << " = -" << tname(tb + T_M_GCF) << " * " << vdiff(q[0], q[3]) << ";\n";
+                break;
+            default: break;
+        }
+    }
+
+    src << i2 << "bool active = !dead && !viol;\n"
+        << i2 << "int it = 0;\n"
+        << i2 << "for (int iter = 0; iter < " << K.tran_max_iters << "; ++iter) {\n"
+        << i2 << "    if (!__any(active)) break;\n";
+    // ---- per-iteration terms: MOS channel (device_common.hpp mos_eval)
+    std::vector<char> xLoaded(static_cast<std::size_t>(N), 0);
+    for (int e = 0; e < ir.n_elems; ++e) {
+        if (ir.kind[e] != CSIM_NMOS && ir.kind[e] != CSIM_PMOS) continue;
+        const int s = ir.param_slot[e], tb = ap.termBase[static_cast<std::size_t>(e)];
+        const int32_t* q = ir.eq + 4 * e;
+        const bool isP = ir.kind[e] == CSIM_PMOS;
+        const std::string m = "m" + std::to_string(e) + "_";
+        for (int tq = 0; tq < 3; ++tq) {
+            if (q[tq] >= 0 && !xLoaded[static_cast<std::size_t>(q[tq])]) {
+                g.out << g.ind << "const double " << xloc(q[tq]) << " = " << xname(q[tq]) << ";\n";
+                xLoaded[static_cast<std::size_t>(q[tq])] = 1;
+            }
+        }
+        const std::string Vd = xloc(q[0]), Vg = xloc(q[1]), Vs = xloc(q[2]);
+        g.out << g.ind << "// MOS element " << e << (isP ? " (PMOS)" : " (NMOS)") << "\n";
+        g.out << g.ind << "const double " << m << "vgs = " << (isP ? "-" : "") << "(" << Vg << " - " << Vs << ");\n"
+              << g.ind << "const double " << m << "vds = " << (isP ? "-" : "") << "(" << Vd << " - " << Vs << ");\n"
+              << g.ind << "const double " << m << "vov = " << m << "vgs - " << pname(s) << ";\n"
+              << g.ind << "const bool " << m << "on = (" << m << "vgs > " << pname(s) << ") && (" << m << "vds >= 0.0);\n"
+              << g.ind << "const bool " << m << "tri = " << m << "vds < " << m << "vov;\n"
+              << g.ind << "const double " << m << "id0 = " << m << "on ? (" << m << "tri ? " << pname(s + 1) << " * (" << m << "vov * " << m
+              << "vds - 0.5 * " << m << "vds * " << m << "vds) : 0.5 * " << pname(s + 1) << " * " << m << "vov * " << m << "vov) : 0.0;\n"
+              << g.ind << "const double " << m << "gds0 = " << m << "on ? (" << m << "tri ? " << pname(s + 1) << " * (" << m << "vov - " << m
+              << "vds) : 0.0) : " << lit(K.mos_off_gds) << ";\n"
+              << g.ind << "const double " << m << "gm0 = " << m << "on ? (" << m << "tri ? " << pname(s + 1) << " * " << m << "vds : "
+              << pname(s + 1) << " * " << m << "vov) : 0.0;\n"
+              << g.ind << "const double " << m << "fac = fmax(1.0 + " << pname(s + 2) << " * " << m << "vds, 0.0);\n"
+              << g.ind << "const double " << tname(tb + T_M_GD) << " = " << m << "gds0 * " << m << "fac + " << m << "id0 * " << pname(s + 2) << ";\n"
+              << g.ind << "const double " << tname(tb + T_M_GG) << " = " << m << "gm0 * " << m << "fac;\n"
+              << g.ind << "const double " << tname(tb + T_M_GS) << " = -(" << tname(tb + T_M_GD) << " + " << tname(tb + T_M_GG) << ");\n"
+              << g.ind << "const double " << tname(tb + T_M_CST) << " = " << (isP ? "-" : "") << "(" << m << "id0 * " << m << "fac) - "
+              << tname(tb + T_M_GD) << " * " << Vd << " - " << tname(tb + T_M_GG) << " * " << Vg << " - " << tname(tb + T_M_GS) << " * " << Vs << ";\n";
+    }
+
+    // ---- assemble [G | I] symbolically (gather lists of plan.cpp, reference order).
+    // Entries are only RECORDED here; the code of an entry is emitted when the
+    // elimination first reads it (shortens live ranges: ~137 entries would
+    // otherwise all be live at once).
+    std::vector<std::vector<AV>> M(static_cast<std::size_t>(N), std::vector<AV>(static_cast<std::size_t>(N + 1)));
+    g.out << g.ind << "// assembly (lazy) + elimination\n";
+    g.pending.assign(static_cast<std::size_t>(N), std::vector<std::vector<AV>>(static_cast<std::size_t>(N + 1)));
+    const GatherPlan& gp = ap.tran;
+    for (int n = 0; n < gp.nnzG(); ++n) {
+        std::vector<AV> terms;
+        for (int c = gp.gPtr[static_cast<std::size_t>(n)]; c < gp.gPtr[static_cast<std::size_t>(n + 1)]; ++c) {
+            const int con = gp.gCon[static_cast<std::size_t>(c)];
+            AV t = termAV[static_cast<std::size_t>(con >> 1)];
+            terms.push_back((con & 1) ? g.negate(t) : t);
+        }
+        const int pos = gp.gPos[static_cast<std::size_t>(n)];
+        g.pending[static_cast<std::size_t>(pos / LD)][static_cast<std::size_t>(pos % LD)] = terms;
+        // structural marker so that zero tests see the entry before it is materialised
+        M[static_cast<std::size_t>(pos / LD)][static_cast<std::size_t>(pos % LD)] = AV::dyn("?");
+    }
+    for (int n = 0; n < gp.nnzI(); ++n) {
+        std::vector<AV> terms;
+        for (int c = gp.iPtr[static_cast<std::size_t>(n)]; c < gp.iPtr[static_cast<std::size_t>(n + 1)]; ++c) {
+            const int con = gp.iCon[static_cast<std::size_t>(c)];
+            AV t = termAV[static_cast<std::size_t>(con >> 1)];
+            terms.push_back((con & 1) ? g.negate(t) : t);
+        }
+        const int r = gp.iRow[static_cast<std::size_t>(n)];
+        g.pending[static_cast<std::size_t>(r)][static_cast<std::size_t>(N)] = terms;
+        M[static_cast<std::size_t>(r)][static_cast<std::size_t>(N)] = AV::dyn("?");
+    }
+    // resolve every all-constant entry now (they cost no code and decide the zero pattern)
+    for (int r = 0; r < N; ++r)
+        for (int c = 0; c <= N; ++c) {
+            auto& pend = g.pending[static_cast<std::size_t>(r)][static_cast<std::size_t>(c)];
+            if (pend.empty()) continue;
+            bool allConst = true;
+            for (const AV& t : pend) allConst = allConst && t.kind != AV::DYN;
+            if (allConst) { M[static_cast<std::size_t>(r)][static_cast<std::size_t>(c)] = g.orderedSum(pend); pend.clear(); }
+        }
+    // materialise on first use
+    auto at = [&](int r, int c) -> AV& {
+        auto& pend = g.pending[static_cast<std::size_t>(r)][static_cast<std::size_t>(c)];
+        AV& slot = M[static_cast<std::size_t>(r)][static_cast<std::size_t>(c)];
+        if (!pend.empty()) { slot = g.orderedSum(pend); pend.clear(); }
+        return slot;
+    };
+
+    // ---- elimination with the scheduled pivots (solver.hpp:46-77), RHS carried along
+    g.out << g.ind << "bool pv = false;     // a pivot check failed in this iteration\n";
+    std::vector<AV> rinv(static_cast<std::size_t>(N));      // 1 / U(k,k)
+    for (int k = 0; k < N; ++k) {
+        const int p = sch.pivotPos[static_cast<std::size_t>(k)];
+        const AV ap_ = at(p, k);
+        g.out << g.ind << "// column " << k << ": pivot row position " << p << "\n";
+        // keep the machine scheduler from pulling later columns' independent work
+        // (assembly sums, MOS terms) to the top of this 3000-instruction block: that
+        // is what inflates the live set to >400 doubles
+        if (std::getenv("CSIM_CG_NOBARRIER") == nullptr) g.out << g.ind << "__builtin_amdgcn_sched_barrier(0);\n";
+        // the reference picks the FIRST row attaining the column maximum (solver.hpp:48-56)
+        // and fails below 1e-15 (:58-61)
+        if (ap_.isZero()) {
+            g.out << g.ind << "pv = true;   // scheduled pivot is a structural zero\n";
+        } else {
+            const std::string absP = ap_.kind == AV::CONST ? lit(std::fabs(ap_.c)) : "fabs(" + ap_.v + ")";
+            if (ap_.kind == AV::DYN) {
+                g.out << g.ind << "pv = pv || !(" << absP << " >= " << lit(K.lu_eps) << ");\n";
+                ++g.st.nCmp;
+            } else if (std::fabs(ap_.c) < K.lu_eps) {
+                g.out << g.ind << "pv = true;\n";
+            }
+            for (int i = k; i < N; ++i) {
+                if (i == p) continue;
+                const AV& ai = at(i, k);
+                if (ai.isZero()) continue;
+                const bool before = i < p;
+                if (ai.kind == AV::CONST && ap_.kind == AV::CONST) {
+                    const bool ok = before ? (std::fabs(ap_.c) > std::fabs(ai.c)) : (std::fabs(ap_.c) >= std::fabs(ai.c));
+                    if (!ok) g.out << g.ind << "pv = true;   // schedule contradicts constant entries\n";
+                    continue;
+                }
+                const std::string absI = ai.kind == AV::CONST ? lit(std::fabs(ai.c)) : "fabs(" + ai.v + ")";
+                g.out << g.ind << "pv = pv || !(" << absP << (before ? " > " : " >= ") << absI << ");\n";
+                ++g.st.nCmp;
+            }
+        }
+        if (p != k) {
+            std::swap(M[static_cast<std::size_t>(p)], M[static_cast<std::size_t>(k)]);
+            std::swap(g.pending[static_cast<std::size_t>(p)], g.pending[static_cast<std::size_t>(k)]);
+        }
+        const AV piv = at(k, k);
+        AV r;
+        if (piv.kind == AV::CONST) r = AV::konst(1.0 / piv.c);
+        else if (piv.kind == AV::DYN) { r = g.emit("rcp_nr(" + g.ref(piv) + ")"); ++g.st.nRecip; }
+        rinv[static_cast<std::size_t>(k)] = r;
+        for (int i = k + 1; i < N; ++i) {
+            const AV aik = at(i, k);
+            if (aik.isZero()) continue;
+            ++g.st.nLower;
+            const AV f = g.mul(aik, r);                                  // multiplier (solver.hpp:71)
+            for (int j = k + 1; j <= N; ++j) {
+                if (M[static_cast<std::size_t>(k)][static_cast<std::size_t>(j)].isZero()) continue;
+                const AV u = at(k, j);
+                if (u.isZero()) continue;
+                const AV a = at(i, j);
+                M[static_cast<std::size_t>(i)][static_cast<std::size_t>(j)] = g.fnma(a, f, u);   // :74
+            }
+            M[static_cast<std::size_t>(i)][static_cast<std::size_t>(k)] = AV::zero();
+        }
+    }
+
+    // ---- back substitution (solver.hpp:116-128): row i descending, j ascending
+    g.out << g.ind << "// back substitution\n";
+    std::vector<AV> xr(static_cast<std::size_t>(N));
+    for (int i = N - 1; i >= 0; --i) {
+        AV sum = at(i, N);
+        for (int j = i + 1; j < N; ++j) {
+            if (M[static_cast<std::size_t>(i)][static_cast<std::size_t>(j)].isZero()) continue;
+            const AV u = at(i, j);
+            if (u.isZero()) continue;
+            if (u.kind == AV::DYN) ++g.st.nDynU;
+            sum = g.fnma(sum, u, xr[static_cast<std::size_t>(j)]);
+        }
+        xr[static_cast<std::size_t>(i)] = g.mul(sum, rinv[static_cast<std::size_t>(i)]);
+    }
+
+    // ---- damped update, norm in index order, convergence (tanalisis.cpp:360-376)
+    std::ostringstream& o = g.out;
+    o << g.ind << "double ss = 0.0;\n";
+    for (int i = 0; i < N; ++i) {
+        const AV& v = xr[static_cast<std::size_t>(i)];
+        o << g.ind << "const double xo" << i << " = X(" << i << ");\n"
+          << g.ind << "const double xn" << i << " = xo" << i << " + " << lit(K.tran_alpha) << " * (" << g.ref(v) << " - xo" << i << ");\n"
+          << g.ind << "{ const double d = xn" << i << " - xo" << i << "; ss += d * d; }\n";
+    }
+    // a non-finite solve (tanalisis.cpp:360-362) makes ss non-finite; so does an overflow of
+    // finite but absurd values -- both are left to the general kernel to classify exactly
+    o << g.ind << "const double err = sqrt(ss);\n"
+      << g.ind << "if (active) {\n"
+      << g.ind << "    if (pv || !(ss < 1.0e300)) { viol = true; active = false; }\n"
+      << g.ind << "    else {\n"
+      << g.ind << "        ++it;\n";
+    for (int i = 0; i < N; ++i) o << g.ind << "        X(" << i << ") = xn" << i << ";\n";
+    o << g.ind << "        if (err < " << lit(K.tran_tol) << ") active = false;\n"
+      << g.ind << "        else if (iter == " << (K.tran_max_iters - 1) << ") st |= ST_TRAN_NONCONV;\n"
+      << g.ind << "    }\n"
+      << g.ind << "}\n";
+
+    src << g.out.str();
+    src << i2 << "}\n"      // NR loop
+        << i2 << "itTotal += it;\n"
+        << i2 << "if (inb && !viol) {\n"
+        << i2 << "    if (stepIters) stepIters[(s - 1) * SB + b] = it;\n"
+        << i2 << "    if (wave && !dead && (gstep % outStride) == 0) {\n"
+        << i2 << "        const long long row = gstep / outStride;\n"
+        << i2 << "        for (int q = 0; q < nProbe; ++q) wave[(row * nProbe + q) * SB + b] = X(probeEq[q]);\n"
+        << i2 << "    }\n"
+        << i2 << "}\n"
+        << "    }\n\n"
+        << "    if (inb) {\n"
+        << "        if (viol) { fallback[b] = 1; }\n"
+        << "        else {\n";
+    for (int i = 0; i < N; ++i) src << "            xio[" << i << "LL * SB + b] = X(" << i << ");\n";
+    src << "            iters[b] += itTotal;\n"
+        << "            status[b] |= st;\n"
+        << "        }\n"
+        << "    }\n"
+        << "}\n\n";
+
+    // ---- launcher + metadata
+    char hbuf[32];
+    std::snprintf(hbuf, sizeof hbuf, "0x%016llxull", static_cast<unsigned long long>(hash));
+    char tbuf[32];
+    std::snprintf(tbuf, sizeof tbuf, "0x%016llxull",
+                  static_cast<unsigned long long>(scheduleHash(ir, PivotSchedule::identity(N))));
+    src << "extern \"C\" unsigned long long csim_sched_hash(void) { return " << hbuf << "; }\n"
+        << "extern \"C\" unsigned long long csim_sched_topology(void) { return " << tbuf << "; }\n"
+        << "extern \"C\" const char* csim_sched_info(void) { return \"" << label << " N=" << N << " schedule="
+        << (sch.str().empty() ? "identity" : sch.str()) << "\"; }\n"
+        << "extern \"C\" int csim_sched_launch(const double* params, int B, double dt, long long stepFirst, long long nSteps,\n"
+        << "                                 const int* probeEq, int nProbe, int outStride, double* wave, double* xio,\n"
+        << "                                 long long* iters, unsigned* status, int* stepIters, unsigned char* fallback,\n"
+        << "                                 void* stream)\n{\n"
+        << "    if (B <= 0) return 0;\n"
+        << "    hipLaunchKernelGGL(csim_tran_sched_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream,\n"
+        << "                       params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
+        << "                       stepIters, fallback);\n"
+        << "    return (int)hipGetLastError();\n}\n";
+
+    if (statsOut) *statsOut = g.st;
+    return src.str();
+}
+
+} // namespace csim

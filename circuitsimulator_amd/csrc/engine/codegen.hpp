@@ -1,0 +1,60 @@
+// codegen.hpp -- generator of circuit-specialised ("scheduled") transient kernels.
+//
+// The general kernels give one 64-lane wavefront to ONE instance and spend it
+// on a dense LDS matrix that is ~90 % zeros.  For a fixed topology the zero
+// pattern, the fill pattern and -- through the whole transient, for every
+// Monte-Carlo instance sampled so far -- the partial-pivot row-swap sequence
+// are the same.  The generator therefore
+// EXECUTES the reference's algorithm symbolically once per circuit:
+//
+//   stamp (src/tanalisis.cpp:269-356) -> luDecompose with the recorded pivot
+//   rows (include/solver.hpp:46-77) -> substitution (:100-128) -> damped
+//   update (src/tanalisis.cpp:365-371)
+//
+// over the abstract domain {structural zero, exact constant, run-time value}
+// and emits straight-line HIP code for the run-time values only.  One LANE
+// owns one instance; the whole working set lives in registers; there is no
+// LDS matrix and no cross-lane traffic.  The emitted code
+//   * performs the same elimination steps in the same order as the reference
+//     (a skipped operation is one whose multiplier or pivot-row entry is a
+//     structural zero: a - 0*b == a; a folded one multiplies by exactly +-1),
+//   * VERIFIES at every column that the scheduled pivot row is the row the
+//     reference would pick (first row attaining the column maximum, and
+//     >= 1e-15); an instance that fails a check is not advanced: it is handed
+//     to the general kernel for that launch and flagged CSIM_ST_SCHED_FALLBACK.
+// Deliberate floating-point differences from the reference (bounded by the
+// 1e-9 parity bar, NR counts must still match): FMA contraction, and
+// multipliers formed with one reciprocal per pivot instead of one division
+// per multiplier.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "csim_ir.h"
+#include "plan.hpp"
+
+namespace csim {
+
+// pivotPos[k] = current row position (>= k) holding the pivot of column k
+struct PivotSchedule {
+    std::vector<int> pivotPos;
+    static PivotSchedule identity(int N);
+    // "k:p,k:p,..." (only the swapped columns), e.g. "0:21,8:22"
+    static bool parse(const std::string& text, int N, PivotSchedule& out);
+    std::string str() const;
+};
+
+// identifies (topology, constants, schedule); names the generated library
+uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch);
+
+struct CodegenStats {
+    int nMul = 0, nFma = 0, nAddSub = 0, nRecip = 0, nCmp = 0, nDynU = 0, nLower = 0;
+};
+
+// complete .hip translation unit: kernel + extern "C" launcher + metadata
+std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch,
+                                     const std::string& label, CodegenStats* stats);
+
+} // namespace csim

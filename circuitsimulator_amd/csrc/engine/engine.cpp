@@ -2,6 +2,7 @@
 // batch entry points.  No CPU arithmetic path exists here: without a usable
 // HIP device csim_engine_create fails (CSIM_ERR_NO_DEVICE).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -9,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "codegen.hpp"
 #include "csim.h"
 #include "engine_internal.hpp"
 #include "kernels.hpp"
@@ -99,6 +101,37 @@ int ensureProbes(csim_engine* eng, const int32_t* probe_eq, int n_probe, const i
     return CSIM_OK;
 }
 
+// directory this shared library was loaded from
+std::string ownDirectory()
+{
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<void*>(&csim_engine_destroy), &info) || !info.dli_fname) return ".";
+    const std::string path(info.dli_fname);
+    const std::size_t slash = path.find_last_of('/');
+    return slash == std::string::npos ? std::string(".") : path.substr(0, slash);
+}
+
+// look for a generated kernel of this topology next to libcsim.so
+void loadScheduledKernel(csim_engine* eng)
+{
+    const csim_ir* ir = eng->cir.view();
+    const unsigned long long topo = csim::scheduleHash(*ir, csim::PivotSchedule::identity(ir->n_unknowns));
+    char name[64];
+    std::snprintf(name, sizeof name, "/libcsim_sched_%016llx.so", topo);
+    const std::string path = ownDirectory() + name;
+    void* lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return;
+    typedef unsigned long long (*HashFn)(void);
+    typedef const char* (*InfoFn)(void);
+    HashFn topoFn = reinterpret_cast<HashFn>(dlsym(lib, "csim_sched_topology"));
+    InfoFn infoFn = reinterpret_cast<InfoFn>(dlsym(lib, "csim_sched_info"));
+    auto launch = reinterpret_cast<csim_engine::SchedLaunchFn>(dlsym(lib, "csim_sched_launch"));
+    if (!topoFn || !launch || topoFn() != topo) { dlclose(lib); return; }
+    eng->schedLib = lib;
+    eng->schedLaunch = launch;
+    eng->schedInfo = infoFn ? infoFn() : "";
+}
+
 } // namespace
 
 extern "C" {
@@ -144,6 +177,7 @@ int csim_engine_create(const csim_netlist* nl, int32_t device, csim_engine** out
     if (!rc) rc = fillGenPlan(eng, eng->plan.dc, eng->gpDc);
     if (!rc) rc = fillGenPlan(eng, eng->plan.tran, eng->gpTran);
     if (rc) { csim_engine_destroy(eng); return rc; }
+    loadScheduledKernel(eng);
     *out = eng;
     return CSIM_OK;
 }
@@ -153,19 +187,24 @@ void csim_engine_destroy(csim_engine* eng)
     if (!eng) return;
     (void)hipSetDevice(eng->device);
     for (void* p : eng->owned) (void)hipFree(p);
+    if (eng->dFallback) (void)hipFree(eng->dFallback);
+    if (eng->schedLib) dlclose(eng->schedLib);
     delete eng;
 }
 
 const char* csim_engine_tran_kernel(const csim_engine* eng)
 {
     if (!eng) return "";
-    return "general";
+    return (eng->schedLaunch && eng->kernelChoice != 1) ? "scheduled" : "general";
 }
 
 int csim_engine_set_kernel(csim_engine* eng, int32_t which)
 {
     if (!eng || which < 0 || which > 2) return CSIM_ERR_ARG;
-    if (which == 2) { setError("no scheduled kernel is available for this circuit"); return CSIM_ERR_UNSUPPORTED; }
+    if (which == 2 && !eng->schedLaunch) {
+        setError("no scheduled kernel is available for this circuit (libcsim_sched_<topology>.so not found)");
+        return CSIM_ERR_UNSUPPORTED;
+    }
     eng->kernelChoice = which;
     return CSIM_OK;
 }
@@ -213,10 +252,27 @@ int csim_tran_batch_dev(csim_engine* eng, const double* d_params, int32_t B, dou
         const int rc = ensureProbes(eng, probe_eq, n_probe, &dProbe);
         if (rc) return rc;
     }
-    HIPCHK(csim::launchTranGeneral(eng->gpTran, d_params, B, tstep, step_first, n_steps, dProbe,
-                                   d_wave ? n_probe : 0, d_wave ? out_stride : 1, d_wave, d_x,
-                                   reinterpret_cast<long long*>(d_iters), d_status, d_step_iters, nullptr,
-                                   static_cast<hipStream_t>(stream)));
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    const int np = d_wave ? n_probe : 0, os = d_wave ? out_stride : 1;
+    const uint8_t* only = nullptr;
+    if (eng->schedLaunch && eng->kernelChoice != 1) {
+        // fast path: lane-per-instance generated kernel; instances whose pivot
+        // checks fail are left untouched and marked in the mask ...
+        if (eng->fallbackCap < B) {
+            if (eng->dFallback) HIPCHK(hipFree(eng->dFallback));
+            eng->dFallback = nullptr;
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dFallback), (size_t)B));
+            eng->fallbackCap = B;
+        }
+        HIPCHK(hipMemsetAsync(eng->dFallback, 0, (size_t)B, hs));
+        const int lrc = eng->schedLaunch(d_params, B, tstep, step_first, n_steps, dProbe, np, os, d_wave, d_x,
+                                         reinterpret_cast<long long*>(d_iters), d_status, d_step_iters,
+                                         eng->dFallback, stream);
+        if (lrc != 0) { setError(std::string("scheduled kernel launch: ") + hipGetErrorString((hipError_t)lrc)); return CSIM_ERR_HIP; }
+        only = eng->dFallback;      // ... and re-run below by the general kernel (blocks of unmarked instances exit at once)
+    }
+    HIPCHK(csim::launchTranGeneral(eng->gpTran, d_params, B, tstep, step_first, n_steps, dProbe, np, os, d_wave, d_x,
+                                   reinterpret_cast<long long*>(d_iters), d_status, d_step_iters, only, hs));
     return CSIM_OK;
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <stdint.h>
+#include <string>
 #include <vector>
 
 #include "../api/circuit.hpp"
@@ -24,6 +25,15 @@ struct csim_engine {
     // Monte-Carlo recipe
     const int32_t* dMcKind = nullptr;
     const double *dNominal = nullptr, *dMu = nullptr, *dCox = nullptr, *dW = nullptr, *dL = nullptr;
+
+    // circuit-specialised transient kernel (side library libcsim_sched_<topology>.so)
+    typedef int (*SchedLaunchFn)(const double*, int, double, long long, long long, const int*, int, int,
+                                 double*, double*, long long*, unsigned*, int*, unsigned char*, void*);
+    void* schedLib = nullptr;
+    SchedLaunchFn schedLaunch = nullptr;
+    std::string schedInfo;
+    unsigned char* dFallback = nullptr;    // per-instance "re-run with the general kernel" mask
+    int fallbackCap = 0;
 
     // probe list of the most recent transient call
     int32_t* dProbe = nullptr;

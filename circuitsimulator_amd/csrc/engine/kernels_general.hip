@@ -160,8 +160,9 @@ k_tran_general(GenPlan pl, const double* __restrict__ params, int B, double dt,
         wave[((int64_t)0 * nProbe + lane) * B + b] = xs[probeEq[lane]];
 
     unsigned st = (status[b] & CSIM_ST_TRAN_NONFINITE);
+    if (only) st |= CSIM_ST_SCHED_FALLBACK;
     long long itTotal = 0;
-    bool aborted = st != 0;                 // an instance the reference would have thrown on stays stopped
+    bool aborted = (st & CSIM_ST_TRAN_NONFINITE) != 0;                 // an instance the reference would have thrown on stays stopped
 
     for (long long s = 1; s <= nSteps && !aborted; ++s) {
         const long long gstep = stepFirst + s;

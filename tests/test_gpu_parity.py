@@ -14,6 +14,7 @@ from conftest import has_gpu, netlist_path, rel_err
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-9
+FALLBACK = 0x20          # CSIM_ST_SCHED_FALLBACK: informational (instance was re-run by the general kernel)
 
 
 @pytest.fixture(scope="module")
@@ -109,7 +110,7 @@ def test_buffer_transient_as_shipped_full_waveform(engines, torch_mod, anchors):
     o = _orc().tran(nl.ir_ptr, nl.n_unknowns, nl.nominal_params, 0, nl.tstep, nl.tstop, want_step_iters=True)
     assert r["iters"][0] == anchors["buffer"]["tran_iters"] == o["iters"]
     assert np.array_equal(r["step_iters"][:, 0], o["step_iters"])
-    assert r["status"][0] == o["status"]
+    assert (r["status"][0] & ~FALLBACK) == o["status"]
     wave = np.transpose(r["wave"], (2, 0, 1))          # [B][rows][N]
     assert np.array_equal(wave[0], wave[1])
     assert rel_err(wave[0], o["rows"][:, 1:], nl.n_node_eq).max() < TOL
@@ -143,7 +144,7 @@ def test_dbmixer_mc_transient_vs_oracle(engines, torch_mod):
         o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstep * steps, want_step_iters=True)
         assert r["iters"][b] == o["iters"], b
         assert np.array_equal(r["step_iters"][:, b], o["step_iters"]), b
-        assert r["status"][b] == o["status"], b
+        assert (r["status"][b] & ~FALLBACK) == o["status"], b
         assert rel_err(r["x"][:, b], o["x_final"], nl.n_node_eq).max() < TOL, b
         ref = o["rows"][::100, 1:][:, nl.probes]
         assert np.abs(r["wave"][:, :, b] - ref).max() <= TOL * np.abs(ref).max()
@@ -162,6 +163,67 @@ def test_dbmixer_full_run_nominal(engines, torch_mod, anchors):
         i = nl.eq_names.index(eqname)
         floor = 1e-6
         assert abs(xf[0][i] - float(s)) <= TOL * max(abs(float(s)), floor)
+
+
+# --------------------------------------- scheduled (lane-per-instance) kernels
+
+def test_shipped_netlists_have_scheduled_kernels(engines):
+    for name in ("buffer", "dbmixer"):
+        nl, eng = engines[name]
+        assert eng.tran_kernel == "scheduled", name
+
+
+def test_scheduled_equals_general_on_mc_batch(engines, torch_mod):
+    """The generated kernel against the dynamic-pivoting general kernel on the same table:
+    equal NR counts per step, states within the parity bar; dbmixer needs no fallback."""
+    nl, eng = engines["dbmixer"]
+    B, steps = 256, 400
+    params = eng.mc_params(777, 0.05, 0, B)
+    eng.set_kernel("scheduled")
+    fast = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+    eng.set_kernel("general")
+    slow = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+    eng.set_kernel("auto")
+    assert np.array_equal(fast["step_iters"], slow["step_iters"])
+    assert np.array_equal(fast["iters"], slow["iters"])
+    assert not (fast["status"] & FALLBACK).any()
+    assert np.array_equal(fast["status"], slow["status"])
+    assert rel_err(fast["x"].T, slow["x"].T, nl.n_node_eq).max() < TOL
+
+
+def test_schedule_violation_falls_back_and_stays_correct(engines, torch_mod):
+    """buffer.sp at its shipped time step switches between 5 pivot sequences (the recorded one
+    is the single sequence of the 10k-step run): the per-factorisation check must catch it, the
+    instance must be re-run by the general kernel and flagged, and results must still match."""
+    nl, eng = engines["buffer"]
+    B = 8
+    params = eng.mc_params(12345, 0.05, 0, B)
+    r = _run_tran(torch_mod, eng, params, 300, nl.tstep, want_step_iters=True)
+    assert (r["status"] & FALLBACK).all()
+    ph = params.cpu().numpy()
+    for b in (0, 3, B - 1):
+        o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstop, want_rows=False, want_step_iters=True)
+        assert r["iters"][b] == o["iters"] and np.array_equal(r["step_iters"][:, b], o["step_iters"])
+        assert rel_err(r["x"][:, b], o["x_final"], nl.n_node_eq).max() < TOL
+    # at 3e-11 s the recorded schedule holds for every factorisation: no fallback
+    r = _run_tran(torch_mod, eng, params, 2000, 3e-11)
+    assert not (r["status"] & FALLBACK).any()
+    o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, 1, 3e-11, 3e-11 * 2000, want_rows=False)
+    assert r["iters"][1] == o["iters"]
+    assert rel_err(r["x"][:, 1], o["x_final"], nl.n_node_eq).max() < TOL
+
+
+def test_scheduled_kernel_ragged_batch(engines, torch_mod):
+    """Batch sizes that do not fill the last wavefront (lane-per-instance packs 64 per wave)."""
+    nl, eng = engines["dbmixer"]
+    ref = None
+    for B in (1, 63, 65, 130):
+        params = eng.mc_params(12345, 0.05, 0, B)
+        r = _run_tran(torch_mod, eng, params, 50, nl.tstep)
+        if ref is None:
+            ref = r
+        assert np.array_equal(r["x"][:, 0], ref["x"][:, 0]) and r["iters"][0] == ref["iters"][0]
+        assert not (r["status"] & 0x27).any()
 
 
 # ------------------------------------- full-size, size-independent properties
@@ -253,7 +315,7 @@ def test_linear_circuit_direct_dc_and_rc_transient(torch_mod):
     assert rel_err(x[0], xo, nl.n_node_eq).max() < TOL
     wave, xf, itr, stt = eng.tran_host(B=2, probes=list(range(nl.n_unknowns)))
     o = _orc().tran(nl.ir_ptr, nl.n_unknowns, nl.nominal_params, 0, nl.tstep, nl.tstop)
-    assert itr[0] == o["iters"] and stt[0] == o["status"]
+    assert itr[0] == o["iters"] and (stt[0] & ~FALLBACK) == o["status"]
     assert rel_err(wave[0], o["rows"][:, 1:], nl.n_node_eq).max() < TOL
 
 
