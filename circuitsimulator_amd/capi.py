@@ -65,6 +65,7 @@ PROTOTYPES = {
     "csim_tran_num_rows": (_i64, [_dbl, _dbl, _dbl, _i32]),
     "csim_tran_num_steps": (_i64, [_dbl, _dbl]),
     "csim_lu_solve_batch": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "csim_lu_decompose_batch": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp]),
 }
 
 

@@ -350,6 +350,58 @@ __device__ __forceinline__ double lu_solve_wave(double* Gm, int N, int LD, doubl
     return xv;
 }
 
+// Solver::luDecompose proper (solver.hpp:30-80): in-place P*A = L*U with the
+// multipliers stored below the diagonal and whole-row swaps, for callers that
+// want the factors.  perm value of row position `lane` is returned in permv.
+__device__ __forceinline__ bool lu_factor_wave(double* Gm, int N, int LD, double eps, int lane, int& permv)
+{
+    permv = lane;
+    for (int k = 0; k < N; ++k) {
+        double colv = (lane < N) ? Gm[lane * LD + k] : 0.0;
+        const double av = fabs(colv);
+        const double akk = read_lane(av, k);
+        int piv = k;
+        double maxAbs = akk;
+        if (akk == akk) {
+            unsigned long long cand = __ballot(lane > k && lane < N && av > 0.0);
+            while (cand) {
+                const int i = __ffsll((long long)cand) - 1;
+                cand &= cand - 1;
+                const double v = read_lane(av, i);
+                if (v > maxAbs) { maxAbs = v; piv = i; }
+            }
+        }
+        if (maxAbs < eps) return false;                              // :58-61
+        if (piv != k) {                                              // :64-67 whole rows + perm
+            if (lane < N) {
+                const double a = Gm[k * LD + lane], b = Gm[piv * LD + lane];
+                Gm[k * LD + lane] = b;
+                Gm[piv * LD + lane] = a;
+            }
+            const double ck = read_lane(colv, k), cp = read_lane(colv, piv);
+            const int pk = __builtin_amdgcn_readlane(permv, __builtin_amdgcn_readfirstlane(k));
+            const int pp = __builtin_amdgcn_readlane(permv, __builtin_amdgcn_readfirstlane(piv));
+            if (lane == k) { colv = cp; permv = pp; }
+            if (lane == piv) { colv = ck; permv = pk; }
+            wave_sync();
+        }
+        const double pivv = read_lane(colv, k);
+        const double rowv = (lane > k && lane < N) ? Gm[k * LD + lane] : 0.0;
+        const bool below = lane > k && lane < N;
+        const double fmine = below ? colv / pivv : 0.0;              // :71
+        if (below) Gm[lane * LD + k] = fmine;                        // :72
+        unsigned long long todo = __ballot(below && colv != 0.0);
+        while (todo) {
+            const int i = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const double f = read_lane(fmine, i);
+            if (lane > k && lane < N) Gm[i * LD + lane] -= f * rowv; // :74
+        }
+        wave_sync();
+    }
+    return true;
+}
+
 // ||v||_2 with the squares summed in index order 0..N-1 (the order of the
 // oracle's norm); sc is an N-double LDS scratch
 __device__ __forceinline__ double norm_in_order(double d, double* sc, int N, int lane)

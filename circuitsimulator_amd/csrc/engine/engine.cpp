@@ -433,4 +433,30 @@ int csim_lu_solve_batch(int32_t device, int32_t n, int32_t B, const double* A, c
     return CSIM_OK;
 }
 
+int csim_lu_decompose_batch(int32_t device, int32_t n, int32_t B, const double* A, double* LU,
+                            int32_t* perm, uint32_t* flags)
+{
+    if (n < 0 || B < 0 || (n > 0 && B > 0 && (!A || !LU || !perm))) { setError("csim_lu_decompose_batch: bad argument"); return CSIM_ERR_ARG; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {
+        setError("csim_lu_decompose_batch: no usable HIP device (this library has no CPU path)");
+        return CSIM_ERR_NO_DEVICE;
+    }
+    if (n == 0 || B == 0) return CSIM_OK;
+    if (n > 63) { setError("csim_lu_decompose_batch covers n <= 63"); return CSIM_ERR_UNSUPPORTED; }
+    HIPCHK(hipSetDevice(device));
+    DevBuf dA, dLU, dP, dF;
+    HIPCHK(dA.alloc(sizeof(double) * (size_t)n * n * B));
+    HIPCHK(dLU.alloc(sizeof(double) * (size_t)n * n * B));
+    HIPCHK(dP.alloc(sizeof(int32_t) * (size_t)n * B));
+    HIPCHK(dF.alloc(sizeof(uint32_t) * (size_t)B));
+    HIPCHK(hipMemcpy(dA.p, A, sizeof(double) * (size_t)n * n * B, hipMemcpyHostToDevice));
+    HIPCHK(csim::launchLuFactor(n, B, dA.as<double>(), dLU.as<double>(), dP.as<int32_t>(), dF.as<uint32_t>(), 1e-15, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(LU, dLU.p, sizeof(double) * (size_t)n * n * B, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(perm, dP.p, sizeof(int32_t) * (size_t)n * B, hipMemcpyDeviceToHost));
+    if (flags) HIPCHK(hipMemcpy(flags, dF.p, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost));
+    return CSIM_OK;
+}
+
 } // extern "C"

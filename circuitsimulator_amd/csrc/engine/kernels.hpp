@@ -18,6 +18,8 @@ hipError_t launchTranGeneral(const GenPlan& pl, const double* dParams, int B, do
                              hipStream_t stream);
 hipError_t launchLuSolve(int n, int B, const double* dA, const double* dRhs, double* dX,
                          uint32_t* dFlags, double eps, hipStream_t stream);
+hipError_t launchLuFactor(int n, int B, const double* dA, double* dLU, int32_t* dPerm, uint32_t* dFlags,
+                          double eps, hipStream_t stream);
 size_t generalLdsBytes(const GenPlan& pl);
 
 // Monte-Carlo parameter table (mc.hip)

@@ -224,7 +224,35 @@ k_lu_solve(int n, int LD, int B, const double* __restrict__ A, const double* __r
     if (flags && lane == 0) flags[b] = st;
 }
 
+// Solver::luDecompose for B matrices (include/solver.hpp:30-80)
+__global__ void __launch_bounds__(64)
+k_lu_factor(int n, int LD, int B, const double* __restrict__ A, double* __restrict__ LU,
+            int32_t* __restrict__ perm, uint32_t* __restrict__ flags, double eps)
+{
+    extern __shared__ double sm[];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    const double* Ab = A + (int64_t)b * n * n;
+    for (int i = lane; i < n * n; i += 64) sm[(i / n) * LD + (i % n)] = Ab[i];
+    wave_sync();
+    int pv = 0;
+    const bool ok = lu_factor_wave(sm, n, LD, eps, lane, pv);
+    wave_sync();
+    for (int i = lane; i < n * n; i += 64) LU[(int64_t)b * n * n + i] = sm[(i / n) * LD + (i % n)];
+    if (lane < n) perm[(int64_t)b * n + lane] = pv;
+    if (flags && lane == 0) flags[b] = ok ? 0u : CSIM_ST_LU_TINY_PIVOT;
+}
+
 // ------------------------------------------------------------------ launchers
+hipError_t launchLuFactor(int n, int B, const double* dA, double* dLU, int32_t* dPerm, uint32_t* dFlags,
+                          double eps, hipStream_t stream)
+{
+    const int LD = ldFor(n);
+    const size_t lds = sizeof(double) * (size_t)n * (size_t)LD;
+    hipLaunchKernelGGL(k_lu_factor, dim3(B), dim3(64), lds, stream, n, LD, B, dA, dLU, dPerm, dFlags, eps);
+    return hipGetLastError();
+}
+
 hipError_t launchDcGeneral(const GenPlan& pl, const double* dParams, int B, double* dX,
                            int32_t* dIters, uint32_t* dStatus, hipStream_t stream)
 {

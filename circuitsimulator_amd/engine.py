@@ -229,3 +229,15 @@ def lu_solve_batch(A, b, device=0):
     capi.check(capi.lib().csim_lu_solve_batch(device, n, B, A.ctypes.data, b.ctypes.data, x.ctypes.data,
                                               flags.ctypes.data))
     return x, flags
+
+
+def lu_decompose_batch(A, device=0):
+    """Batched Solver::luDecompose on the GPU.  A [B][n][n] -> (LU [B][n][n], perm [B][n], flags [B])."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    B, n, _ = A.shape
+    LU = np.zeros_like(A)
+    perm = np.zeros((B, n), dtype=np.int32)
+    flags = np.zeros(B, dtype=np.uint32)
+    capi.check(capi.lib().csim_lu_decompose_batch(device, n, B, A.ctypes.data, LU.ctypes.data, perm.ctypes.data,
+                                                  flags.ctypes.data))
+    return LU, perm, flags

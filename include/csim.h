@@ -155,6 +155,13 @@ int64_t csim_tran_num_steps(double tstep, double tstop);
 int  csim_lu_solve_batch(int32_t device, int32_t n, int32_t B, const double* A,
                          const double* b, double* x, uint32_t* flags);
 
+/* Batched Solver::luDecompose (include/solver.hpp:30-80): LU [B][n][n] holds U on
+ * and above the diagonal and the multipliers below it, perm [B][n] the row
+ * permutation (b_perm[i] = b[perm[i]]).  flags[b] = CSIM_ST_LU_TINY_PIVOT where
+ * the reference returns false (LU/perm of that system are then unspecified).  */
+int  csim_lu_decompose_batch(int32_t device, int32_t n, int32_t B, const double* A,
+                             double* LU, int32_t* perm, uint32_t* flags);
+
 #ifdef __cplusplus
 }
 #endif

@@ -370,3 +370,48 @@ def test_lu_pivot_tie_takes_first_row():
     for i in range(2):
         xo, fo = _orc().solve_lu(A[i], b[i])
         assert np.array_equal(x[i], xo) and flags[i] == fo
+
+
+def test_lu_decompose_factors_bitwise_equal_to_oracle():
+    """Solver::luDecompose: packed L\\U and the permutation, same bits as the oracle."""
+    from circuitsimulator_amd import lu_decompose_batch
+    rs = np.random.RandomState(11)
+    for n in (1, 3, 13, 31, 63):
+        B = 6
+        A = rs.randn(B, n, n)
+        A[rs.rand(B, n, n) < 0.5] = 0.0
+        A += np.eye(n)[None] * 0.5
+        if n > 1:
+            A[1] = A[1][::-1].copy()                     # force pivoting
+        LU, perm, flags = lu_decompose_batch(A)
+        for i in range(B):
+            ok, LUo, permo = _orc().lu_decompose(A[i])
+            assert bool(flags[i] & 0x4) == (not ok)
+            if ok:
+                assert np.array_equal(perm[i], permo), (n, i)
+                assert np.array_equal(LU[i], LUo), (n, i, np.abs(LU[i] - LUo).max())
+    LU, perm, flags = lu_decompose_batch(np.array([[[1.0, 2.0], [2.0, 4.0]]]))
+    assert flags[0] & 0x4
+
+
+def test_cli_writes_the_reference_csv(tmp_path, buffer_nl):
+    """csim_cli = the reference's main.cpp phases over the C++ shims (parseNetlist,
+    computeDcOperatingPoint, runTransientAnalysisBackwardEuler) -> the reference's CSV."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "circuitsimulator_amd", "csim_cli")
+    out = str(tmp_path / "tran.csv")
+    p = subprocess.run([exe, netlist_path("buffer.sp"), out], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "Unknowns     : 13  (nodeEq=9, branchEq=4)" in p.stdout
+    assert "V(107) = 2.490044 V   [eqIndex=3]" in p.stdout
+    assert "I(L2, 117 -> 118)" in p.stdout and "[branchEq=12]" in p.stdout
+    lines = open(out).read().strip().split("\\n")
+    assert lines[0] == buffer_nl.csv_header
+    rows = np.array([[float(v) for v in l.split(",")] for l in lines[1:]])
+    o = _orc().tran(buffer_nl.ir_ptr, 13, buffer_nl.nominal_params, 0, buffer_nl.tstep, buffer_nl.tstop)
+    assert rows.shape == o["rows"].shape
+    assert np.array_equal(rows[:, 0], np.array([float("%.9e" % t) for t in o["rows"][:, 0]]))
+    assert np.abs(rows[:, 1:] - o["rows"][:, 1:]).max() <= 6e-10 * np.abs(o["rows"][:, 1:]).max()
+    assert all(len(l.split(",")[1].split("e")[0]) in (11, 12) for l in lines[1:4])   # 9 decimals, scientific
