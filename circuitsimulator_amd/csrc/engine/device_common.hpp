@@ -265,8 +265,15 @@ __device__ __forceinline__ void assemble(const GenPlan& pl, const double* T, dou
 // ascending-j summation order.
 //
 // Returns the solution component of lane i (< N) and ORs CSIM_ST_LU_* flags.
-__device__ __forceinline__ double lu_solve_wave(double* Gm, int N, int LD, double eps, int lane, unsigned& flags)
+//
+// pivLog (optional, planner): int32 [N + 2] in global memory: the pivot row position of
+// every column for the FIRST factorisation seen, then the number of factorisations and
+// the number whose sequence differed from the first.
+__device__ __forceinline__ double lu_solve_wave(double* Gm, int N, int LD, double eps, int lane, unsigned& flags,
+                                                int32_t* pivLog = nullptr)
 {
+    const bool logFirst = pivLog && pivLog[N] == 0;
+    bool logDiffer = false;
     double diag = 1.0;          // lane k keeps U(k,k)
     bool failed = false;
 
@@ -290,6 +297,10 @@ __device__ __forceinline__ double lu_solve_wave(double* Gm, int N, int LD, doubl
             }
         }
         if (maxAbs < eps) { failed = true; break; }
+        if (pivLog) {
+            if (logFirst) { if (lane == 0) pivLog[k] = piv; }
+            else if (pivLog[k] != piv) logDiffer = true;
+        }
 
         if (piv != k) {         // swap rows k and piv (columns >= k and the RHS)
             if (lane >= k && lane <= N) {
@@ -320,6 +331,10 @@ __device__ __forceinline__ double lu_solve_wave(double* Gm, int N, int LD, doubl
         wave_sync();
     }
 
+    if (pivLog && lane == 0) {
+        pivLog[N] += 1;
+        if (logDiffer || (failed && !logFirst)) pivLog[N + 1] += 1;
+    }
     if (failed) {
         flags |= CSIM_ST_LU_TINY_PIVOT;
         return 0.0;

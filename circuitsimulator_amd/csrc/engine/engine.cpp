@@ -433,6 +433,44 @@ int csim_lu_solve_batch(int32_t device, int32_t n, int32_t B, const double* A, c
     return CSIM_OK;
 }
 
+int csim_record_pivot_schedule(csim_engine* eng, const double* d_params, int32_t B, int32_t instance,
+                               double tstep, int64_t n_steps, int32_t* pivot_pos, int64_t* n_factorizations,
+                               int64_t* n_differ)
+{
+    if (!eng || !d_params || !pivot_pos || B <= 0 || instance < 0 || instance >= B || n_steps < 0 || !(tstep > 0.0)) {
+        setError("csim_record_pivot_schedule: bad argument");
+        return CSIM_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(eng->device));
+    const int N = eng->plan.N;
+    DevBuf dX, dIt32, dIt, dSt, dLog;
+    HIPCHK(dX.alloc(sizeof(double) * (size_t)N * B));
+    HIPCHK(dIt32.alloc(sizeof(int32_t) * (size_t)B));
+    HIPCHK(dIt.alloc(sizeof(int64_t) * (size_t)B));
+    HIPCHK(dSt.alloc(sizeof(uint32_t) * (size_t)B));
+    HIPCHK(dLog.alloc(sizeof(int32_t) * (size_t)(N + 2)));
+    HIPCHK(hipMemset(dIt.p, 0, sizeof(int64_t) * (size_t)B));
+    HIPCHK(hipMemset(dLog.p, 0, sizeof(int32_t) * (size_t)(N + 2)));
+    int rc = csim_dc_batch_dev(eng, d_params, B, dX.as<double>(), dIt32.as<int32_t>(), dSt.as<uint32_t>(), nullptr);
+    if (rc) return rc;
+    // only the chosen instance runs (mask), with the pivot log attached
+    DevBuf dOnly;
+    HIPCHK(dOnly.alloc((size_t)B));
+    HIPCHK(hipMemset(dOnly.p, 0, (size_t)B));
+    const unsigned char one = 1;
+    HIPCHK(hipMemcpy(dOnly.as<unsigned char>() + instance, &one, 1, hipMemcpyHostToDevice));
+    HIPCHK(csim::launchTranGeneral(eng->gpTran, d_params, B, tstep, 0, n_steps, nullptr, 0, 1, nullptr, dX.as<double>(),
+                                   dIt.as<long long>(), dSt.as<uint32_t>(), nullptr, dOnly.as<uint8_t>(), nullptr,
+                                   dLog.as<int32_t>(), instance));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<int32_t> log((size_t)N + 2);
+    HIPCHK(hipMemcpy(log.data(), dLog.p, sizeof(int32_t) * log.size(), hipMemcpyDeviceToHost));
+    for (int k = 0; k < N; ++k) pivot_pos[k] = log[(size_t)k];
+    if (n_factorizations) *n_factorizations = log[(size_t)N];
+    if (n_differ) *n_differ = log[(size_t)N + 1];
+    return CSIM_OK;
+}
+
 int csim_lu_decompose_batch(int32_t device, int32_t n, int32_t B, const double* A, double* LU,
                             int32_t* perm, uint32_t* flags)
 {

@@ -128,12 +128,14 @@ k_tran_general(GenPlan pl, const double* __restrict__ params, int B, double dt,
                const int32_t* __restrict__ probeEq, int nProbe, int outStride,
                double* __restrict__ wave, double* __restrict__ xio,
                long long* __restrict__ iters, uint32_t* __restrict__ status,
-               int32_t* __restrict__ stepIters, const uint8_t* __restrict__ only)
+               int32_t* __restrict__ stepIters, const uint8_t* __restrict__ only,
+               int32_t* __restrict__ pivLog, int pivInstance)
 {
     extern __shared__ double sm[];
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     if (only && !only[b]) return;           // fallback launches touch flagged instances only
+    int32_t* myPivLog = (pivLog && b == pivInstance) ? pivLog : nullptr;
     const int N = pl.N, LD = pl.LD;
     const LdsLayout L = ldsLayout(N, LD, pl.nTerms, pl.P);
     double* Gm = sm + L.G;
@@ -174,7 +176,7 @@ k_tran_general(GenPlan pl, const double* __restrict__ params, int B, double dt,
             terms_iter_mos(pl, Pv, T, xs, lane);
             wave_sync();
             assemble(pl, T, Gm, lane);                                  // :259-356
-            const double xr = lu_solve_wave(Gm, N, LD, K.lu_eps, lane, st);   // :359
+            const double xr = lu_solve_wave(Gm, N, LD, K.lu_eps, lane, st, myPivLog);   // :359
             ++it;
             if (!wave_all_finite(xr, N, lane)) {                        // :360-362
                 st |= CSIM_ST_TRAN_NONFINITE;
@@ -266,12 +268,12 @@ hipError_t launchTranGeneral(const GenPlan& pl, const double* dParams, int B, do
                              long long stepFirst, long long nSteps, const int32_t* dProbeEq, int nProbe,
                              int outStride, double* dWave, double* dX, long long* dIters,
                              uint32_t* dStatus, int32_t* dStepIters, const uint8_t* dOnly,
-                             hipStream_t stream)
+                             hipStream_t stream, int32_t* dPivLog, int pivInstance)
 {
     const LdsLayout L = ldsLayout(pl.N, pl.LD, pl.nTerms, pl.P);
     const size_t lds = sizeof(double) * (size_t)L.total;
     hipLaunchKernelGGL(k_tran_general, dim3(B), dim3(64), lds, stream, pl, dParams, B, dt, stepFirst, nSteps,
-                       dProbeEq, nProbe, outStride, dWave, dX, dIters, dStatus, dStepIters, dOnly);
+                       dProbeEq, nProbe, outStride, dWave, dX, dIters, dStatus, dStepIters, dOnly, dPivLog, pivInstance);
     return hipGetLastError();
 }
 

@@ -207,6 +207,18 @@ class Engine:
             st.ctypes.data))
         return wave, xf, it, st
 
+    def record_pivot_schedule(self, params, instance=0, tstep=None, n_steps=200):
+        """Planner: pivot row position per column of the first transient factorisation of one
+        instance (general kernel), as (schedule string, #factorisations, #with another sequence)."""
+        tstep = self.netlist.tstep if tstep is None else tstep
+        pos = np.zeros(self.N, dtype=np.int32)
+        nlu, ndiff = C.c_int64(), C.c_int64()
+        capi.check(capi.lib().csim_record_pivot_schedule(self._h, params.data_ptr(), params.shape[1], instance,
+                                                         float(tstep), int(n_steps), pos.ctypes.data,
+                                                         C.byref(nlu), C.byref(ndiff)))
+        sched = ",".join("%d:%d" % (k, p) for k, p in enumerate(pos) if p != k)
+        return sched, nlu.value, ndiff.value
+
     def close(self):
         if self._h:
             capi.lib().csim_engine_destroy(self._h)

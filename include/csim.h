@@ -162,6 +162,15 @@ int  csim_lu_solve_batch(int32_t device, int32_t n, int32_t B, const double* A,
 int  csim_lu_decompose_batch(int32_t device, int32_t n, int32_t B, const double* A,
                              double* LU, int32_t* perm, uint32_t* flags);
 
+/* Planner: run DC + n_steps transient steps of ONE instance (column `instance` of
+ * d_params) with the general kernel and report the partial-pivot row position chosen
+ * for every column in the first transient factorisation (pivot_pos[N], host), the
+ * number of factorisations seen and how many used a different sequence.  This is what
+ * a schedule file of csrc/schedules/ is recorded from.                              */
+int  csim_record_pivot_schedule(csim_engine* eng, const double* d_params /*[P][B]*/, int32_t B,
+                                int32_t instance, double tstep, int64_t n_steps,
+                                int32_t* pivot_pos, int64_t* n_factorizations, int64_t* n_differ);
+
 #ifdef __cplusplus
 }
 #endif

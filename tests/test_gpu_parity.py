@@ -407,7 +407,7 @@ def test_cli_writes_the_reference_csv(tmp_path, buffer_nl):
     assert "Unknowns     : 13  (nodeEq=9, branchEq=4)" in p.stdout
     assert "V(107) = 2.490044 V   [eqIndex=3]" in p.stdout
     assert "I(L2, 117 -> 118)" in p.stdout and "[branchEq=12]" in p.stdout
-    lines = open(out).read().strip().split("\\n")
+    lines = open(out).read().strip().split("\n")
     assert lines[0] == buffer_nl.csv_header
     rows = np.array([[float(v) for v in l.split(",")] for l in lines[1:]])
     o = _orc().tran(buffer_nl.ir_ptr, 13, buffer_nl.nominal_params, 0, buffer_nl.tstep, buffer_nl.tstop)
@@ -415,3 +415,26 @@ def test_cli_writes_the_reference_csv(tmp_path, buffer_nl):
     assert np.array_equal(rows[:, 0], np.array([float("%.9e" % t) for t in o["rows"][:, 0]]))
     assert np.abs(rows[:, 1:] - o["rows"][:, 1:]).max() <= 6e-10 * np.abs(o["rows"][:, 1:]).max()
     assert all(len(l.split(",")[1].split("e")[0]) in (11, 12) for l in lines[1:4])   # 9 decimals, scientific
+
+
+def test_committed_schedules_match_the_planner(engines, torch_mod):
+    """csrc/schedules/*.sched are what the general kernel's planner records on this GPU, and equal
+    SURVEY.md Appendix F; dbmixer keeps one sequence through the run, also under MC perturbation."""
+    import os
+    from conftest import ROOT
+
+    def committed(name):
+        txt = open(os.path.join(ROOT, "circuitsimulator_amd", "csrc", "schedules", name + ".sched")).read()
+        return ",".join(l.strip() for l in txt.splitlines() if l.strip() and not l.startswith("#"))
+
+    nl, eng = engines["dbmixer"]
+    params = eng.mc_params(12345, 0.05, 0, 4)
+    for b in range(4):
+        sched, nlu, ndiff = eng.record_pivot_schedule(params, b, None, 1500)
+        assert sched == committed("dbmixer") and ndiff == 0 and nlu > 10000
+    nl, eng = engines["buffer"]
+    params = eng.mc_params(12345, 0.05, 0, 2)
+    sched, nlu, ndiff = eng.record_pivot_schedule(params, 0, 3e-11, 3000)
+    assert sched == committed("buffer") and ndiff == 0
+    sched, nlu, ndiff = eng.record_pivot_schedule(params, 0, 1e-9, 300)     # as shipped: several sequences
+    assert ndiff > 0
