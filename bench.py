@@ -38,6 +38,22 @@ def algorithmic_bytes_per_iter(N):
     return 8 * (N * N + 3 * N)
 
 
+def hbm_traffic_per_launch(nl, kernel, B, S):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json,
+    written by tools/summarize_profile.py; FETCH_SIZE/WRITE_SIZE collected in separate passes and
+    corrected as MI355X_MICROARCH.md prescribes).  None when this exact workload was not profiled."""
+    path = os.path.join(HERE, "profiles", "hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    key = "N%d|%s|B%d|S%d" % (nl.n_unknowns, kernel, B, S)
+    ent = table.get(key)
+    return ent["bytes_per_launch"] if ent else None
+
+
 def cpu_baseline(nl, params_host, n_inst, tstep, n_tsteps):
     """Oracle (CPU restatement, 1 thread) on a bounded sample of the same workload."""
     from oracle import binding as orc
@@ -63,6 +79,8 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "general", "scheduled"])
     ap.add_argument("--cpu-iters", type=float, default=1.2e6, help="approx. NR iterations of the CPU sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--large-batch", type=int, default=65536,
+                    help="also time this many instances per GPU (one wave per SIMD needs >= 65536); 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -136,6 +154,33 @@ def main():
     torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - t0) * 1e3
 
+    # ---- second leg: a batch that gives every SIMD a wave (same circuit, same kernels) ------
+    large = None
+    if args.large_batch and args.large_batch != B:
+        BL = args.large_batch
+        pl = eng.mc_params(args.seed, args.sigma, rank * BL, BL)
+        xl, _, stl = eng.dc(pl)
+        itl = torch.zeros(BL, dtype=torch.int64, device=dev)
+        eng.tran(pl, xl, tstep, 0, S, itl, stl)                  # warm-up step
+        torch.cuda.synchronize()
+        shard.barrier()
+        before = itl.clone()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nl_steps = max(1, args.steps // 2)
+        t0 = time.perf_counter()
+        e0.record()
+        for k in range(nl_steps):
+            eng.tran(pl, xl, tstep, S * (1 + k), S, itl, stl)
+        e1.record()
+        torch.cuda.synchronize()
+        shard.barrier()
+        wl = shard.all_reduce_max(time.perf_counter() - t0, device=dev)
+        il = shard.all_reduce_sum(float((itl - before).sum().item()), device=dev)
+        large = {"batch_per_gpu": BL, "value": il / wl, "steps": nl_steps,
+                 "kernel_avg_ms": e0.elapsed_time(e1) / nl_steps,
+                 "flagged_instances": int((stl & 0x27).ne(0).sum().item())}
+        del pl, xl, itl, stl
+
     if rank == 0:
         value = total_iters / wall_max
         avg_kern_s = float(np.mean(kern_ms)) * 1e-3
@@ -171,7 +216,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": hbm_traffic_per_launch(nl, eng.tran_kernel, B, S),
                 "algorithmic_bytes_per_unit": abytes,
                 "kernel_avg_ms": avg_kern_s * 1e3,
             },
@@ -179,6 +224,9 @@ def main():
             "result_gather_ms": gather_ms,
             "gathered_shape": list(all_v.shape),
         }
+        if large is not None:
+            large["roofline_frac"] = large["value"] * abytes / 1e9 / HBM_PEAK_GBS
+            rec["large_batch"] = large
         if world == 1 and not args.no_cpu:
             # CPU baseline: the oracle (port of the reference algorithm), 1 thread,
             # on the first instances of the same parameter table

@@ -210,13 +210,20 @@ std::string vdiff(int a, int b)
 
 // ------------------------------------------------------------------ generator
 
-std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch,
-                                     const std::string& label, CodegenStats* statsOut)
+namespace {
+
+struct VariantOptions {
+    const char* kernelName;
+    bool rich;      // park finished U rows / reciprocals / RHS and the launch constants in LDS
+};
+
+// emits ONE __global__ kernel; returns the number of LDS doubles per lane it uses
+int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch,
+               const VariantOptions& opt, CodegenStats* statsOut)
 {
     const int N = ir.n_unknowns;
     const int LD = ap.LD;
     const csim_consts& K = ir.k;
-    const uint64_t hash = scheduleHash(ir, sch);
     Gen g(ir, ap);
 
     // term -> abstract value.  Exact constants: the global ONE term and the
@@ -234,15 +241,6 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         if (ir.kind[e] == CSIM_NMOS || ir.kind[e] == CSIM_PMOS)
             for (int o = T_M_GD; o <= T_M_CST; ++o)
                 invariant[static_cast<std::size_t>(ap.termBase[static_cast<std::size_t>(e)] + o)] = 0;
-
-    std::ostringstream src;
-    src << "// GENERATED by circuitsimulator_amd/csrc/engine/codegen.cpp -- do not edit.\n"
-        << "// circuit: " << label << "   N=" << N << "  elements=" << ir.n_elems << "  P=" << ir.n_params << "\n"
-        << "// pivot schedule (column:row position): " << (sch.str().empty() ? "identity" : sch.str()) << "\n"
-        << "// One lane = one circuit instance; see codegen.hpp for what is and is not\n"
-        << "// identical to the reference arithmetic.\n"
-        << "#include <hip/hip_runtime.h>\n#include <stdint.h>\n\n"
-        << "#define ST_TRAN_NONFINITE 0x0001u\n#define ST_TRAN_NONCONV 0x0002u\n\n";
 
     // ---- which terms are per-step (sources, history currents): they live in LDS too
     std::vector<int> stepSlot(static_cast<std::size_t>(ap.nTerms), -1);
@@ -263,23 +261,52 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     for (int t = 0; t < ap.nTerms; ++t)
         if (stepSlot[static_cast<std::size_t>(t)] >= 0) termAV[static_cast<std::size_t>(t)] = AV::dyn(sname(t));
 
-    // LDS layout: lds[slot*64 + lane]; slots 0..N-1 = x, N.. = per-step terms.  Every
+    // LDS layout: lds[slot*64 + lane]; slots 0..N-1 = x, N.. = per-step terms, then (rich
+    // variant) launch constants, parameters used inside the loops and parked U rows.  Every
     // lane only ever touches its own column, so no barrier or fence is needed.
-    src << "#define X(i) lds[(i) * 64 + lane]\n#define S(j) lds[(" << N << " + (j)) * 64 + lane]\n\n"
-        << "// Newton-refined reciprocal (v_rcp_f64 + 2 FMA pairs, ~1 ulp) for the pivots\n"
-        << "__device__ __forceinline__ double rcp_nr(double a)\n{\n"
-        << "    double r = __builtin_amdgcn_rcp(a);\n"
-        << "    r = fma(fma(-a, r, 1.0), r, r);\n"
-        << "    r = fma(fma(-a, r, 1.0), r, r);\n"
-        << "    return r;\n}\n\n";
+    int ldsNext = N + nStep;       // next free LDS slot (doubles per lane)
+    auto qslot = [&]() { return "Q(" + std::to_string(ldsNext++) + ")"; };
+    // parameters / launch terms referenced inside the time loop: registers (lean) or LDS (rich)
+    std::vector<std::string> pRef(static_cast<std::size_t>(ir.n_params));
+    for (int p = 0; p < ir.n_params; ++p) pRef[static_cast<std::size_t>(p)] = pname(p);
+    std::vector<std::string> tRef(static_cast<std::size_t>(ap.nTerms));
+    for (int t = 0; t < ap.nTerms; ++t) tRef[static_cast<std::size_t>(t)] = tname(t);
+    std::ostringstream ldsInit;    // stores that fill the rich variant's LDS copies
+    auto toLdsParam = [&](int p) {
+        if (!opt.rich || pRef[static_cast<std::size_t>(p)][0] == 'Q') return;
+        const std::string q = qslot();
+        ldsInit << "    " << q << " = " << pname(p) << ";\n";
+        pRef[static_cast<std::size_t>(p)] = q;
+    };
+    auto toLdsTerm = [&](int t) {
+        if (!opt.rich) return;
+        const std::string q = qslot();
+        ldsInit << "    " << q << " = " << tname(t) << ";\n";
+        tRef[static_cast<std::size_t>(t)] = q;
+        termAV[static_cast<std::size_t>(t)] = AV::dyn(q);
+    };
+    for (int e = 0; e < ir.n_elems; ++e) {
+        const int sl = ir.param_slot[e], tb = ap.termBase[static_cast<std::size_t>(e)];
+        switch (ir.kind[e]) {
+            case CSIM_R: toLdsTerm(tb + T_R_G); break;
+            case CSIM_C: toLdsTerm(tb + T_C_GC); break;
+            case CSIM_L: toLdsTerm(tb + T_L_REQ); break;
+            case CSIM_V: case CSIM_I: for (int o = 0; o < 6; ++o) toLdsParam(sl + o); break;
+            case CSIM_NMOS: case CSIM_PMOS:
+                toLdsTerm(tb + T_M_GCH); toLdsTerm(tb + T_M_GCF);
+                for (int o = 0; o < 3; ++o) toLdsParam(sl + o);
+                break;
+            default: break;
+        }
+    }
 
     src << "extern \"C\" __global__ void __launch_bounds__(64)\n"
-        << "csim_tran_sched_kernel(const double* __restrict__ params, int B, double dt, long long stepFirst,\n"
+        << opt.kernelName << "(const double* __restrict__ params, int B, double dt, long long stepFirst,\n"
         << "                       long long nSteps, const int* __restrict__ probeEq, int nProbe, int outStride,\n"
         << "                       double* __restrict__ wave, double* __restrict__ xio, long long* __restrict__ iters,\n"
         << "                       unsigned* __restrict__ status, int* __restrict__ stepIters,\n"
         << "                       unsigned char* __restrict__ fallback)\n{\n"
-        << "    __shared__ double lds[" << (N + nStep) << " * 64];\n"
+        << "    __shared__ double lds[@LDS_DOUBLES@ * 64];\n"
         << "    const int lane = threadIdx.x;\n"
         << "    const int b = blockIdx.x * 64 + threadIdx.x;\n"
         << "    const bool inb = b < B;\n"
@@ -314,6 +341,7 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         }
     }
     src << "    const double " << tname(ap.termGmin) << " = " << lit(K.tran_gmin) << ";\n";
+    src << ldsInit.str();
 
     // ---- state
     for (int i = 0; i < N; ++i) src << "    X(" << i << ") = xio[" << i << "LL * SB + bb];\n";
@@ -336,25 +364,25 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         switch (ir.kind[e]) {
             case CSIM_V: case CSIM_I:
                 if (ir.wave[e] == CSIM_WAVE_SIN) {
-                    src << i2 << "if (tNow < " << pname(s + 4) << ") " << sname(tb) << " = " << pname(s) << " + " << pname(s + 1) << ";\n"
-                        << i2 << "else " << sname(tb) << " = " << pname(s) << " + (" << pname(s + 1) << " + " << pname(s + 2)
-                        << " * sin((2.0 * " << lit(K.pi) << " * " << pname(s + 3) << ") * (tNow - " << pname(s + 4) << ") + "
-                        << pname(s + 5) << "));\n";
+                    src << i2 << "if (tNow < " << pRef[static_cast<std::size_t>(s + 4)] << ") " << sname(tb) << " = " << pRef[static_cast<std::size_t>(s)] << " + " << pRef[static_cast<std::size_t>(s + 1)] << ";\n"
+                        << i2 << "else " << sname(tb) << " = " << pRef[static_cast<std::size_t>(s)] << " + (" << pRef[static_cast<std::size_t>(s + 1)] << " + " << pRef[static_cast<std::size_t>(s + 2)]
+                        << " * sin((2.0 * " << lit(K.pi) << " * " << pRef[static_cast<std::size_t>(s + 3)] << ") * (tNow - " << pRef[static_cast<std::size_t>(s + 4)] << ") + "
+                        << pRef[static_cast<std::size_t>(s + 5)] << "));\n";
                 } else {
-                    src << i2 << sname(tb) << " = " << pname(s) << " + 0.0;\n";
+                    src << i2 << sname(tb) << " = " << pRef[static_cast<std::size_t>(s)] << " + 0.0;\n";
                 }
                 break;
             case CSIM_C:
-                src << i2 << sname(tb + T_C_IH) << " = -" << tname(tb + T_C_GC) << " * " << vdiff(q[0], q[1]) << ";\n";
+                src << i2 << sname(tb + T_C_IH) << " = -" << tRef[static_cast<std::size_t>(tb + T_C_GC)] << " * " << vdiff(q[0], q[1]) << ";\n";
                 break;
             case CSIM_L:
-                src << i2 << sname(tb + T_L_VH) << " = -" << tname(tb + T_L_REQ) << " * X(" << ir.branch_eq[e] << ");\n";
+                src << i2 << sname(tb + T_L_VH) << " = -" << tRef[static_cast<std::size_t>(tb + T_L_REQ)] << " * X(" << ir.branch_eq[e] << ");\n";
                 break;
             case CSIM_NMOS: case CSIM_PMOS:
-                src << i2 << sname(tb + T_M_IHGS) << " = -" << tname(tb + T_M_GCH) << " * " << vdiff(q[1], q[2]) << ";\n"
-                    << i2 << sname(tb + T_M_IHGD) << " = -" << tname(tb + T_M_GCH) << " * " << vdiff(q[1], q[0]) << ";\n"
-                    << i2 << sname(tb + T_M_IHSB) << " = -" << tname(tb + T_M_GCF) << " * " << vdiff(q[2], q[3]) << ";\n"
-                    << i2 << sname(tb + T_M_IHDB) << " = -" << tname(tb + T_M_GCF) << " * " << vdiff(q[0], q[3]) << ";\n";
+                src << i2 << sname(tb + T_M_IHGS) << " = -" << tRef[static_cast<std::size_t>(tb + T_M_GCH)] << " * " << vdiff(q[1], q[2]) << ";\n"
+                    << i2 << sname(tb + T_M_IHGD) << " = -" << tRef[static_cast<std::size_t>(tb + T_M_GCH)] << " * " << vdiff(q[1], q[0]) << ";\n"
+                    << i2 << sname(tb + T_M_IHSB) << " = -" << tRef[static_cast<std::size_t>(tb + T_M_GCF)] << " * " << vdiff(q[2], q[3]) << ";\n"
+                    << i2 << sname(tb + T_M_IHDB) << " = -" << tRef[static_cast<std::size_t>(tb + T_M_GCF)] << " * " << vdiff(q[0], q[3]) << ";\n";
                 break;
             default: break;
         }
@@ -379,20 +407,24 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
             }
         }
         const std::string Vd = xloc(q[0]), Vg = xloc(q[1]), Vs = xloc(q[2]);
+        const std::string pVth = "m" + std::to_string(e) + "_vth", pK = "m" + std::to_string(e) + "_k",
+                          pLam = "m" + std::to_string(e) + "_lam";
+        g.out << g.ind << "const double " << pVth << " = " << pRef[static_cast<std::size_t>(s)] << ", " << pK << " = "
+              << pRef[static_cast<std::size_t>(s + 1)] << ", " << pLam << " = " << pRef[static_cast<std::size_t>(s + 2)] << ";\n";
         g.out << g.ind << "// MOS element " << e << (isP ? " (PMOS)" : " (NMOS)") << "\n";
         g.out << g.ind << "const double " << m << "vgs = " << (isP ? "-" : "") << "(" << Vg << " - " << Vs << ");\n"
               << g.ind << "const double " << m << "vds = " << (isP ? "-" : "") << "(" << Vd << " - " << Vs << ");\n"
-              << g.ind << "const double " << m << "vov = " << m << "vgs - " << pname(s) << ";\n"
-              << g.ind << "const bool " << m << "on = (" << m << "vgs > " << pname(s) << ") && (" << m << "vds >= 0.0);\n"
+              << g.ind << "const double " << m << "vov = " << m << "vgs - " << pVth << ";\n"
+              << g.ind << "const bool " << m << "on = (" << m << "vgs > " << pVth << ") && (" << m << "vds >= 0.0);\n"
               << g.ind << "const bool " << m << "tri = " << m << "vds < " << m << "vov;\n"
-              << g.ind << "const double " << m << "id0 = " << m << "on ? (" << m << "tri ? " << pname(s + 1) << " * (" << m << "vov * " << m
-              << "vds - 0.5 * " << m << "vds * " << m << "vds) : 0.5 * " << pname(s + 1) << " * " << m << "vov * " << m << "vov) : 0.0;\n"
-              << g.ind << "const double " << m << "gds0 = " << m << "on ? (" << m << "tri ? " << pname(s + 1) << " * (" << m << "vov - " << m
+              << g.ind << "const double " << m << "id0 = " << m << "on ? (" << m << "tri ? " << pK << " * (" << m << "vov * " << m
+              << "vds - 0.5 * " << m << "vds * " << m << "vds) : 0.5 * " << pK << " * " << m << "vov * " << m << "vov) : 0.0;\n"
+              << g.ind << "const double " << m << "gds0 = " << m << "on ? (" << m << "tri ? " << pK << " * (" << m << "vov - " << m
               << "vds) : 0.0) : " << lit(K.mos_off_gds) << ";\n"
-              << g.ind << "const double " << m << "gm0 = " << m << "on ? (" << m << "tri ? " << pname(s + 1) << " * " << m << "vds : "
-              << pname(s + 1) << " * " << m << "vov) : 0.0;\n"
-              << g.ind << "const double " << m << "fac = fmax(1.0 + " << pname(s + 2) << " * " << m << "vds, 0.0);\n"
-              << g.ind << "const double " << tname(tb + T_M_GD) << " = " << m << "gds0 * " << m << "fac + " << m << "id0 * " << pname(s + 2) << ";\n"
+              << g.ind << "const double " << m << "gm0 = " << m << "on ? (" << m << "tri ? " << pK << " * " << m << "vds : "
+              << pK << " * " << m << "vov) : 0.0;\n"
+              << g.ind << "const double " << m << "fac = fmax(1.0 + " << pLam << " * " << m << "vds, 0.0);\n"
+              << g.ind << "const double " << tname(tb + T_M_GD) << " = " << m << "gds0 * " << m << "fac + " << m << "id0 * " << pLam << ";\n"
               << g.ind << "const double " << tname(tb + T_M_GG) << " = " << m << "gm0 * " << m << "fac;\n"
               << g.ind << "const double " << tname(tb + T_M_GS) << " = -(" << tname(tb + T_M_GD) << " + " << tname(tb + T_M_GG) << ");\n"
               << g.ind << "const double " << tname(tb + T_M_CST) << " = " << (isP ? "-" : "") << "(" << m << "id0 * " << m << "fac) - "
@@ -508,6 +540,24 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
             }
             M[static_cast<std::size_t>(i)][static_cast<std::size_t>(k)] = AV::zero();
         }
+        // row k is final: it is next read in the back substitution.  The rich variant parks
+        // its run-time entries (and the pivot reciprocal) in LDS instead of leaving it to the
+        // register allocator to spill them to scratch.
+        if (opt.rich) {
+            for (int j = k + 1; j <= N; ++j) {
+                if (M[static_cast<std::size_t>(k)][static_cast<std::size_t>(j)].isZero()) continue;
+                const AV v = at(k, j);
+                if (v.kind != AV::DYN) continue;
+                const std::string q = qslot();
+                g.out << g.ind << q << " = " << g.ref(v) << ";\n";
+                M[static_cast<std::size_t>(k)][static_cast<std::size_t>(j)] = AV::dyn(q);
+            }
+            if (r.kind == AV::DYN) {
+                const std::string q = qslot();
+                g.out << g.ind << q << " = " << g.ref(r) << ";\n";
+                rinv[static_cast<std::size_t>(k)] = AV::dyn(q);
+            }
+        }
     }
 
     // ---- back substitution (solver.hpp:116-128): row i descending, j ascending
@@ -568,7 +618,51 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "    }\n"
         << "}\n\n";
 
-    // ---- launcher + metadata
+    if (statsOut) *statsOut = g.st;
+    return ldsNext;
+}
+
+} // namespace
+
+std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch,
+                                     const std::string& label, CodegenStats* statsOut)
+{
+    const int N = ir.n_unknowns;
+    const uint64_t hash = scheduleHash(ir, sch);
+    std::ostringstream src;
+    src << "// GENERATED by circuitsimulator_amd/csrc/engine/codegen.cpp -- do not edit.\n"
+        << "// circuit: " << label << "   N=" << N << "  elements=" << ir.n_elems << "  P=" << ir.n_params << "\n"
+        << "// pivot schedule (column:row position): " << (sch.str().empty() ? "identity" : sch.str()) << "\n"
+        << "// One lane = one circuit instance; see codegen.hpp for what is and is not\n"
+        << "// identical to the reference arithmetic.  Two variants of the same arithmetic:\n"
+        << "//   csim_tran_sched_kernel       x and per-step terms in LDS (<= 40 KB per wave: 4 waves/CU)\n"
+        << "//   csim_tran_sched_kernel_rich  additionally parks launch constants, loop parameters and\n"
+        << "//                                finished U rows in LDS (one wave per CU; used when the batch\n"
+        << "//                                has no more waves than the chip has CUs)\n"
+        << "#include <hip/hip_runtime.h>\n#include <stdint.h>\n\n"
+        << "#define ST_TRAN_NONFINITE 0x0001u\n#define ST_TRAN_NONCONV 0x0002u\n\n"
+        << "#define Q(k) lds[(k) * 64 + lane]\n#define X(i) Q(i)\n#define S(j) Q(" << N << " + (j))\n\n"
+        << "// Newton-refined reciprocal (v_rcp_f64 + 2 FMA pairs, ~1 ulp) for the pivots\n"
+        << "__device__ __forceinline__ double rcp_nr(double a)\n{\n"
+        << "    double r = __builtin_amdgcn_rcp(a);\n"
+        << "    r = fma(fma(-a, r, 1.0), r, r);\n"
+        << "    r = fma(fma(-a, r, 1.0), r, r);\n"
+        << "    return r;\n}\n\n";
+
+    auto emitVariant = [&](const VariantOptions& opt, CodegenStats* st) {
+        std::ostringstream k;
+        const int ldsDoubles = emitKernel(k, ir, ap, sch, opt, st);
+        std::string text = k.str();
+        const std::string token = "@LDS_DOUBLES@";
+        const std::size_t at = text.find(token);
+        text.replace(at, token.size(), std::to_string(ldsDoubles));
+        src << text;
+        return ldsDoubles;
+    };
+    const int ldsLean = emitVariant({"csim_tran_sched_kernel", false}, statsOut);
+    int ldsRich = emitVariant({"csim_tran_sched_kernel_rich", true}, nullptr);
+    const bool haveRich = ldsRich * 512 <= 160 * 1024;      // must fit one CU's LDS
+
     char hbuf[32];
     std::snprintf(hbuf, sizeof hbuf, "0x%016llxull", static_cast<unsigned long long>(hash));
     char tbuf[32];
@@ -577,18 +671,26 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     src << "extern \"C\" unsigned long long csim_sched_hash(void) { return " << hbuf << "; }\n"
         << "extern \"C\" unsigned long long csim_sched_topology(void) { return " << tbuf << "; }\n"
         << "extern \"C\" const char* csim_sched_info(void) { return \"" << label << " N=" << N << " schedule="
-        << (sch.str().empty() ? "identity" : sch.str()) << "\"; }\n"
+        << (sch.str().empty() ? "identity" : sch.str()) << " lds_doubles_per_lane=" << ldsLean << "/" << ldsRich << "\"; }\n"
+        << "// variant: 0 = by batch size, 1 = lean, 2 = rich\n"
         << "extern \"C\" int csim_sched_launch(const double* params, int B, double dt, long long stepFirst, long long nSteps,\n"
         << "                                 const int* probeEq, int nProbe, int outStride, double* wave, double* xio,\n"
         << "                                 long long* iters, unsigned* status, int* stepIters, unsigned char* fallback,\n"
-        << "                                 void* stream)\n{\n"
+        << "                                 void* stream, int variant)\n{\n"
         << "    if (B <= 0) return 0;\n"
-        << "    hipLaunchKernelGGL(csim_tran_sched_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream,\n"
-        << "                       params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
-        << "                       stepIters, fallback);\n"
+        << "    const unsigned waves = (unsigned)((B + 63) / 64);\n"
+        << "    int cus = 256;\n"
+        << "    { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; }\n"
+        << "    const bool rich = " << (haveRich ? "(variant == 2) || (variant == 0 && waves <= (unsigned)cus)" : "false") << ";\n"
+        << "    if (rich)\n"
+        << "        hipLaunchKernelGGL(csim_tran_sched_kernel_rich, dim3(waves), dim3(64), 0, (hipStream_t)stream,\n"
+        << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
+        << "                           stepIters, fallback);\n"
+        << "    else\n"
+        << "        hipLaunchKernelGGL(csim_tran_sched_kernel, dim3(waves), dim3(64), 0, (hipStream_t)stream,\n"
+        << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
+        << "                           stepIters, fallback);\n"
         << "    return (int)hipGetLastError();\n}\n";
-
-    if (statsOut) *statsOut = g.st;
     return src.str();
 }
 

@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -130,6 +131,7 @@ void loadScheduledKernel(csim_engine* eng)
     eng->schedLib = lib;
     eng->schedLaunch = launch;
     eng->schedInfo = infoFn ? infoFn() : "";
+    if (const char* v = std::getenv("CSIM_SCHED_VARIANT")) eng->schedVariant = std::atoi(v);
 }
 
 } // namespace
@@ -267,7 +269,7 @@ int csim_tran_batch_dev(csim_engine* eng, const double* d_params, int32_t B, dou
         HIPCHK(hipMemsetAsync(eng->dFallback, 0, (size_t)B, hs));
         const int lrc = eng->schedLaunch(d_params, B, tstep, step_first, n_steps, dProbe, np, os, d_wave, d_x,
                                          reinterpret_cast<long long*>(d_iters), d_status, d_step_iters,
-                                         eng->dFallback, stream);
+                                         eng->dFallback, stream, eng->schedVariant);
         if (lrc != 0) { setError(std::string("scheduled kernel launch: ") + hipGetErrorString((hipError_t)lrc)); return CSIM_ERR_HIP; }
         only = eng->dFallback;      // ... and re-run below by the general kernel (blocks of unmarked instances exit at once)
     }

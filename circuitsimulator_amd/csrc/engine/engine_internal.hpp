@@ -12,6 +12,7 @@
 struct csim_engine {
     int device = 0;
     int kernelChoice = 0;                  // 0 auto, 1 general, 2 scheduled
+    int schedVariant = 0;                  // 0 by batch size, 1 lean, 2 rich (CSIM_SCHED_VARIANT)
     csim::CircuitIR cir;                   // private copy of the flattened circuit
     csim::AssemblyPlan plan;
 
@@ -28,7 +29,7 @@ struct csim_engine {
 
     // circuit-specialised transient kernel (side library libcsim_sched_<topology>.so)
     typedef int (*SchedLaunchFn)(const double*, int, double, long long, long long, const int*, int, int,
-                                 double*, double*, long long*, unsigned*, int*, unsigned char*, void*);
+                                 double*, double*, long long*, unsigned*, int*, unsigned char*, void*, int);
     void* schedLib = nullptr;
     SchedLaunchFn schedLaunch = nullptr;
     std::string schedInfo;
