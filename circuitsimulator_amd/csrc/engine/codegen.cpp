@@ -214,7 +214,9 @@ namespace {
 
 struct VariantOptions {
     const char* kernelName;
-    bool rich;      // park finished U rows / reciprocals / RHS and the launch constants in LDS
+    bool rich;          // launch constants and loop parameters in LDS
+    bool stepInLds;     // per-step terms (sources, history currents) in LDS (else registers)
+    int parkBudget;     // how many finished U-row values may be parked in LDS (-1 = all)
 };
 
 // emits ONE __global__ kernel; returns the number of LDS doubles per lane it uses
@@ -257,7 +259,11 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             default: break;
         }
     }
-    auto sname = [&](int t) { return "S(" + std::to_string(stepSlot[static_cast<std::size_t>(t)]) + ")"; };
+    if (!opt.stepInLds) nStep = 0;     // per-step terms stay in registers: plain variables st<j>
+    auto sname = [&](int t) {
+        const std::string j = std::to_string(stepSlot[static_cast<std::size_t>(t)]);
+        return opt.stepInLds ? "S(" + j + ")" : "st" + j;
+    };
     for (int t = 0; t < ap.nTerms; ++t)
         if (stepSlot[static_cast<std::size_t>(t)] >= 0) termAV[static_cast<std::size_t>(t)] = AV::dyn(sname(t));
 
@@ -291,7 +297,17 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             case CSIM_R: toLdsTerm(tb + T_R_G); break;
             case CSIM_C: toLdsTerm(tb + T_C_GC); break;
             case CSIM_L: toLdsTerm(tb + T_L_REQ); break;
-            case CSIM_V: case CSIM_I: for (int o = 0; o < 6; ++o) toLdsParam(sl + o); break;
+            case CSIM_V: case CSIM_I:
+                for (int o = 0; o < 6; ++o) {
+                    toLdsParam(sl + o);
+                    // lean: source parameters are needed once per time step only -- re-read them
+                    // from the table (L2-resident) instead of pinning 6 doubles per source in
+                    // registers for the whole kernel; volatile keeps LICM from hoisting the load
+                    if (!opt.rich)
+                        pRef[static_cast<std::size_t>(sl + o)] =
+                            "(*(const volatile double*)&params[" + std::to_string(sl + o) + "LL * SB + bb])";
+                }
+                break;
             case CSIM_NMOS: case CSIM_PMOS:
                 toLdsTerm(tb + T_M_GCH); toLdsTerm(tb + T_M_GCF);
                 for (int o = 0; o < 3; ++o) toLdsParam(sl + o);
@@ -314,8 +330,10 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         << "    const long long SB = B;\n";
 
     // ---- parameters
-    for (int p = 0; p < ir.n_params; ++p)
+    for (int p = 0; p < ir.n_params; ++p) {
+        if (pRef[static_cast<std::size_t>(p)][0] == '(') continue;        // re-read at its use
         src << "    const double " << pname(p) << " = params[" << p << "LL * SB + bb];\n";
+    }
 
     // ---- launch-constant terms (device_common.hpp terms_const<true>)
     src << "    bool viol = false;      // pivot schedule (or a precondition of it) violated -> general kernel\n";
@@ -356,8 +374,11 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         << "        const long long gstep = stepFirst + s;\n"
         << "        const double tNow = (double)(int)gstep * dt;\n";
 
-    // ---- per-step terms (device_common.hpp terms_step_tran), stored to LDS
+    // ---- per-step terms (device_common.hpp terms_step_tran), stored to LDS or kept in registers
     const std::string i2 = "        ";
+    if (!opt.stepInLds)
+        for (int t = 0; t < ap.nTerms; ++t)
+            if (stepSlot[static_cast<std::size_t>(t)] >= 0) src << i2 << "double " << sname(t) << ";\n";
     for (int e = 0; e < ir.n_elems; ++e) {
         const int s = ir.param_slot[e], tb = ap.termBase[static_cast<std::size_t>(e)];
         const int32_t* q = ir.eq + 4 * e;
@@ -482,6 +503,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
     // ---- elimination with the scheduled pivots (solver.hpp:46-77), RHS carried along
     g.out << g.ind << "bool pv = false;     // a pivot check failed in this iteration\n";
     std::vector<AV> rinv(static_cast<std::size_t>(N));      // 1 / U(k,k)
+    int parked = 0;
     for (int k = 0; k < N; ++k) {
         const int p = sch.pivotPos[static_cast<std::size_t>(k)];
         const AV ap_ = at(p, k);
@@ -543,16 +565,19 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         // row k is final: it is next read in the back substitution.  The rich variant parks
         // its run-time entries (and the pivot reciprocal) in LDS instead of leaving it to the
         // register allocator to spill them to scratch.
-        if (opt.rich) {
+        if (opt.parkBudget != 0) {
             for (int j = k + 1; j <= N; ++j) {
                 if (M[static_cast<std::size_t>(k)][static_cast<std::size_t>(j)].isZero()) continue;
                 const AV v = at(k, j);
                 if (v.kind != AV::DYN) continue;
+                if (opt.parkBudget > 0 && parked >= opt.parkBudget) break;
+                ++parked;
                 const std::string q = qslot();
                 g.out << g.ind << q << " = " << g.ref(v) << ";\n";
                 M[static_cast<std::size_t>(k)][static_cast<std::size_t>(j)] = AV::dyn(q);
             }
-            if (r.kind == AV::DYN) {
+            if (r.kind == AV::DYN && (opt.parkBudget < 0 || parked < opt.parkBudget)) {
+                ++parked;
                 const std::string q = qslot();
                 g.out << g.ind << q << " = " << g.ref(r) << ";\n";
                 rinv[static_cast<std::size_t>(k)] = AV::dyn(q);
@@ -659,8 +684,10 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         src << text;
         return ldsDoubles;
     };
-    const int ldsLean = emitVariant({"csim_tran_sched_kernel", false}, statsOut);
-    int ldsRich = emitVariant({"csim_tran_sched_kernel_rich", true}, nullptr);
+    // lean: 40 KB of LDS per wave (4 waves per CU): x, then finished U rows up to the budget
+    const int leanBudget = 80 - N;
+    const int ldsLean = emitVariant({"csim_tran_sched_kernel", false, false, leanBudget > 0 ? leanBudget : 0}, statsOut);
+    int ldsRich = emitVariant({"csim_tran_sched_kernel_rich", true, true, -1}, nullptr);
     const bool haveRich = ldsRich * 512 <= 160 * 1024;      // must fit one CU's LDS
 
     char hbuf[32];
