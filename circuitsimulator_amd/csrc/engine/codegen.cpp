@@ -660,10 +660,10 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "// pivot schedule (column:row position): " << (sch.str().empty() ? "identity" : sch.str()) << "\n"
         << "// One lane = one circuit instance; see codegen.hpp for what is and is not\n"
         << "// identical to the reference arithmetic.  Two variants of the same arithmetic:\n"
-        << "//   csim_tran_sched_kernel       x and per-step terms in LDS (<= 40 KB per wave: 4 waves/CU)\n"
-        << "//   csim_tran_sched_kernel_rich  additionally parks launch constants, loop parameters and\n"
-        << "//                                finished U rows in LDS (one wave per CU; used when the batch\n"
-        << "//                                has no more waves than the chip has CUs)\n"
+        << "//   csim_tran_sched_kernel       x and as many finished U-row values as fit 40 KB of LDS per\n"
+        << "//                                wave (4 waves per CU, one per SIMD)\n"
+        << "//   csim_tran_sched_kernel_rich  every finished U-row value parked in LDS (tuning aid: measured\n"
+        << "//                                slower -- ds traffic costs more than the spills it removes)\n"
         << "#include <hip/hip_runtime.h>\n#include <stdint.h>\n\n"
         << "#define ST_TRAN_NONFINITE 0x0001u\n#define ST_TRAN_NONCONV 0x0002u\n\n"
         << "#define Q(k) lds[(k) * 64 + lane]\n#define X(i) Q(i)\n#define S(j) Q(" << N << " + (j))\n\n"
@@ -687,8 +687,20 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     // lean: 40 KB of LDS per wave (4 waves per CU): x, then finished U rows up to the budget
     const int leanBudget = 80 - N;
     const int ldsLean = emitVariant({"csim_tran_sched_kernel", false, false, leanBudget > 0 ? leanBudget : 0}, statsOut);
-    int ldsRich = emitVariant({"csim_tran_sched_kernel_rich", true, true, -1}, nullptr);
+    // rich: same residency, every finished U row parked (more LDS per wave: fewer waves per CU)
+    int ldsRich = emitVariant({"csim_tran_sched_kernel_rich", false, false, -1}, nullptr);
     const bool haveRich = ldsRich * 512 <= 160 * 1024;      // must fit one CU's LDS
+    std::vector<int> sweep;
+    if (const char* sw = std::getenv("CSIM_CG_SWEEP")) {      // tuning aid: "0,8,16,24,32" park budgets
+        std::string t(sw);
+        std::size_t i = 0;
+        while (i < t.size()) { sweep.push_back(std::atoi(t.c_str() + i)); i = t.find(',', i); if (i == std::string::npos) break; ++i; }
+        for (std::size_t k = 0; k < sweep.size(); ++k) {
+            static std::vector<std::string> names;
+            names.push_back("csim_tran_sched_kernel_sweep" + std::to_string(k));
+            emitVariant({names.back().c_str(), false, false, sweep[k]}, nullptr);
+        }
+    }
 
     char hbuf[32];
     std::snprintf(hbuf, sizeof hbuf, "0x%016llxull", static_cast<unsigned long long>(hash));
@@ -699,17 +711,20 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "extern \"C\" unsigned long long csim_sched_topology(void) { return " << tbuf << "; }\n"
         << "extern \"C\" const char* csim_sched_info(void) { return \"" << label << " N=" << N << " schedule="
         << (sch.str().empty() ? "identity" : sch.str()) << " lds_doubles_per_lane=" << ldsLean << "/" << ldsRich << "\"; }\n"
-        << "// variant: 0 = by batch size, 1 = lean, 2 = rich\n"
+        << "// variant: 0/1 = lean (measured fastest at every batch size: park-budget sweep in DESIGN.md),\n"
+        << "//          2 = rich (tuning aid), 10+k = sweep kernels when generated with CSIM_CG_SWEEP\n"
         << "extern \"C\" int csim_sched_launch(const double* params, int B, double dt, long long stepFirst, long long nSteps,\n"
         << "                                 const int* probeEq, int nProbe, int outStride, double* wave, double* xio,\n"
         << "                                 long long* iters, unsigned* status, int* stepIters, unsigned char* fallback,\n"
         << "                                 void* stream, int variant)\n{\n"
         << "    if (B <= 0) return 0;\n"
         << "    const unsigned waves = (unsigned)((B + 63) / 64);\n"
-        << "    int cus = 256;\n"
-        << "    { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; }\n"
-        << "    const bool rich = " << (haveRich ? "(variant == 2) || (variant == 0 && waves <= (unsigned)cus)" : "false") << ";\n"
-        << "    if (rich)\n"
+        << "    const bool rich = " << (haveRich ? "(variant == 2)" : "false") << ";\n"
+        ;
+    for (std::size_t k = 0; k < sweep.size(); ++k)
+        src << "    if (variant == " << (10 + k) << ") { hipLaunchKernelGGL(csim_tran_sched_kernel_sweep" << k
+            << ", dim3(waves), dim3(64), 0, (hipStream_t)stream, params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status, stepIters, fallback); return (int)hipGetLastError(); }\n";
+    src << "    if (rich)\n"
         << "        hipLaunchKernelGGL(csim_tran_sched_kernel_rich, dim3(waves), dim3(64), 0, (hipStream_t)stream,\n"
         << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
         << "                           stepIters, fallback);\n"
