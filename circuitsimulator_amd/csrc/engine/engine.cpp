@@ -473,6 +473,56 @@ int csim_record_pivot_schedule(csim_engine* eng, const double* d_params, int32_t
     return CSIM_OK;
 }
 
+int csim_engine_jit_scheduled(csim_engine* eng, const double* d_params, int32_t B, double tstep, int64_t plan_steps)
+{
+    if (!eng || !d_params || B <= 0 || !(tstep > 0.0) || plan_steps <= 0) { setError("csim_engine_jit_scheduled: bad argument"); return CSIM_ERR_ARG; }
+    const csim_ir* ir = eng->cir.view();
+    const int N = ir->n_unknowns;
+    std::vector<int32_t> pos((size_t)N);
+    int64_t nlu = 0, ndiff = 0;
+    int rc = csim_record_pivot_schedule(eng, d_params, B, 0, tstep, plan_steps, pos.data(), &nlu, &ndiff);
+    if (rc) return rc;
+    if (nlu == 0) { setError("planner saw no factorisation"); return CSIM_ERR_UNSUPPORTED; }
+    csim::PivotSchedule sch = csim::PivotSchedule::identity(N);
+    for (int k = 0; k < N; ++k) sch.pivotPos[(size_t)k] = pos[(size_t)k];
+
+    const unsigned long long topo = csim::scheduleHash(*ir, csim::PivotSchedule::identity(N));
+    const unsigned long long full = csim::scheduleHash(*ir, sch);
+    const char* dirEnv = std::getenv("CSIM_JIT_DIR");
+    const std::string dir = dirEnv ? dirEnv : "/tmp/csim_jit";
+    char stem[96];
+    std::snprintf(stem, sizeof stem, "/libcsim_sched_%016llx_%016llx", topo, full);
+    const std::string lib = dir + stem + ".so", hip = dir + stem + ".hip", log = dir + stem + ".log";
+
+    void* handle = dlopen(lib.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!handle) {
+        if (std::system(("mkdir -p '" + dir + "'").c_str()) != 0) { setError("cannot create " + dir); return CSIM_ERR_IO; }
+        const std::string src = csim::generateTranKernelSource(*ir, eng->plan, sch, "jit", nullptr);
+        FILE* f = std::fopen(hip.c_str(), "w");
+        if (!f) { setError("cannot write " + hip); return CSIM_ERR_IO; }
+        std::fwrite(src.data(), 1, src.size(), f);
+        std::fclose(f);
+        const char* ccEnv = std::getenv("CSIM_HIPCC");
+        const std::string cc = ccEnv ? ccEnv : "/opt/rocm/bin/hipcc";
+        const std::string cmd = cc + " -O3 -std=c++17 -fPIC --offload-arch=gfx950 -shared '" + hip + "' -o '" + lib +
+                                ".tmp' > '" + log + "' 2>&1 && mv '" + lib + ".tmp' '" + lib + "'";
+        if (std::system(cmd.c_str()) != 0) { setError("hipcc failed, see " + log); return CSIM_ERR_UNSUPPORTED; }
+        handle = dlopen(lib.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!handle) { setError(std::string("dlopen: ") + dlerror()); return CSIM_ERR_IO; }
+    }
+    typedef unsigned long long (*HashFn)(void);
+    typedef const char* (*InfoFn)(void);
+    HashFn topoFn = reinterpret_cast<HashFn>(dlsym(handle, "csim_sched_topology"));
+    InfoFn infoFn = reinterpret_cast<InfoFn>(dlsym(handle, "csim_sched_info"));
+    auto launch = reinterpret_cast<csim_engine::SchedLaunchFn>(dlsym(handle, "csim_sched_launch"));
+    if (!topoFn || !launch || topoFn() != topo) { dlclose(handle); setError("generated library does not match the circuit"); return CSIM_ERR_UNSUPPORTED; }
+    if (eng->schedLib) dlclose(eng->schedLib);
+    eng->schedLib = handle;
+    eng->schedLaunch = launch;
+    eng->schedInfo = infoFn ? infoFn() : "";
+    return CSIM_OK;
+}
+
 int csim_lu_decompose_batch(int32_t device, int32_t n, int32_t B, const double* A, double* LU,
                             int32_t* perm, uint32_t* flags)
 {

@@ -207,6 +207,12 @@ class Engine:
             st.ctypes.data))
         return wave, xf, it, st
 
+    def jit_scheduled(self, params, tstep=None, plan_steps=200):
+        """Plan + generate + hipcc + load the lane-per-instance kernel for this netlist (needs hipcc)."""
+        tstep = self.netlist.tstep if tstep is None else tstep
+        capi.check(capi.lib().csim_engine_jit_scheduled(self._h, params.data_ptr(), params.shape[1], float(tstep),
+                                                        int(plan_steps)))
+
     def record_pivot_schedule(self, params, instance=0, tstep=None, n_steps=200):
         """Planner: pivot row position per column of the first transient factorisation of one
         instance (general kernel), as (schedule string, #factorisations, #with another sequence)."""

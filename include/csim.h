@@ -155,6 +155,16 @@ int64_t csim_tran_num_steps(double tstep, double tstop);
 int  csim_lu_solve_batch(int32_t device, int32_t n, int32_t B, const double* A,
                          const double* b, double* x, uint32_t* flags);
 
+/* Runtime specialisation for a netlist without a prebuilt libcsim_sched_<topology>.so:
+ * records the pivot schedule of instance 0 of d_params with the general kernel
+ * (plan_steps transient steps), generates the lane-per-instance kernel, compiles it
+ * with hipcc (--offload-arch=gfx950; $CSIM_HIPCC overrides the compiler path) into
+ * $CSIM_JIT_DIR (default /tmp/csim_jit) and loads it.  A cached library of the same
+ * (topology, constants, schedule) hash is reused.  After CSIM_OK,
+ * csim_engine_tran_kernel() reports "scheduled".                                  */
+int  csim_engine_jit_scheduled(csim_engine* eng, const double* d_params /*[P][B]*/, int32_t B,
+                               double tstep, int64_t plan_steps);
+
 /* Batched Solver::luDecompose (include/solver.hpp:30-80): LU [B][n][n] holds U on
  * and above the diagonal and the multipliers below it, perm [B][n] the row
  * permutation (b_perm[i] = b[perm[i]]).  flags[b] = CSIM_ST_LU_TINY_PIVOT where

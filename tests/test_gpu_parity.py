@@ -438,3 +438,56 @@ def test_committed_schedules_match_the_planner(engines, torch_mod):
     assert sched == committed("buffer") and ndiff == 0
     sched, nlu, ndiff = eng.record_pivot_schedule(params, 0, 1e-9, 300)     # as shipped: several sequences
     assert ndiff > 0
+
+
+INVERTER_CHAIN = """* three CMOS inverters driving an RC line (not one of the shipped netlists)
+VDD vdd 0 DC 2.5
+Vin in 0 SIN 1.25 1.0 50e6 0
+Rg in g1 100
+M1 o1 g1 vdd p 40e-6 0.5e-6 1
+M2 o1 g1 0   n 20e-6 0.5e-6 2
+M3 o2 o1 vdd p 40e-6 0.5e-6 1
+M4 o2 o1 0   n 20e-6 0.5e-6 2
+M5 o3 o2 vdd p 40e-6 0.5e-6 1
+M6 o3 o2 0   n 20e-6 0.5e-6 2
+R1 o3 l1 50
+L1 l1 l2 2e-9
+C1 l2 0 0.2e-12
+R2 l2 out 75
+C2 out 0 0.5e-12
+.MODEL 1 VT -0.6 MU 2e-2 COX 2e-3 LAMBDA 0.04 CJ0 2e-14
+.MODEL 2 VT 0.55 MU 6e-2 COX 2e-3 LAMBDA 0.04 CJ0 2e-14
+.TRAN 2e-12 4e-9
+.plotnv out
+"""
+
+
+def test_jit_scheduled_kernel_for_a_new_netlist(torch_mod, tmp_path, monkeypatch):
+    """A netlist with no prebuilt kernel: plan with the general kernel, generate, hipcc, load;
+    then scheduled == general == oracle."""
+    import shutil
+    from circuitsimulator_amd import Engine, Netlist
+    if not (shutil.which("hipcc") or __import__("os").path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available for the JIT")
+    monkeypatch.setenv("CSIM_JIT_DIR", str(tmp_path / "jit"))
+    nl = Netlist.from_text(INVERTER_CHAIN)
+    eng = Engine(nl, 0)
+    assert eng.tran_kernel == "general"
+    B, steps = 96, 600
+    params = eng.mc_params(4242, 0.05, 0, B)
+    slow = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+    eng.jit_scheduled(params, plan_steps=300)
+    assert eng.tran_kernel == "scheduled"
+    fast = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+    assert np.array_equal(fast["step_iters"], slow["step_iters"])
+    assert np.array_equal(fast["status"] & NOFB, slow["status"])
+    assert rel_err(fast["x"].T, slow["x"].T, nl.n_node_eq).max() < TOL
+    assert ((fast["status"] & FALLBACK) != 0).sum() < B // 2      # the fast path really ran for most
+    ph = params.cpu().numpy()
+    o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, 5, nl.tstep, nl.tstep * steps, want_rows=False)
+    assert fast["iters"][5] == o["iters"]
+    assert rel_err(fast["x"][:, 5], o["x_final"], nl.n_node_eq).max() < TOL
+    # second engine: the cached library is reused (no compile)
+    eng2 = Engine(nl, 0)
+    eng2.jit_scheduled(params, plan_steps=300)
+    assert eng2.tran_kernel == "scheduled"
