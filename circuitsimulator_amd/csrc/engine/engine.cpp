@@ -102,6 +102,21 @@ int ensureProbes(csim_engine* eng, const int32_t* probe_eq, int n_probe, const i
     return CSIM_OK;
 }
 
+// zeroed N x LD scratch matrix per instance for the large-N kernels
+int ensureBigScratch(csim_engine* eng, int B, hipStream_t hs)
+{
+    if (!eng->big || eng->bigScratchCap >= B) return CSIM_OK;
+    const size_t per = csim::bigScratchBytesPerInstance(eng->gpTran);
+    if (per * (size_t)B > (size_t)96 << 30) { setError("batch too large for the large-N scratch matrices (96 GiB cap)"); return CSIM_ERR_UNSUPPORTED; }
+    if (eng->dBigScratch) HIPCHK(hipFree(eng->dBigScratch));
+    eng->dBigScratch = nullptr;
+    eng->bigScratchCap = 0;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dBigScratch), per * (size_t)B));
+    HIPCHK(hipMemsetAsync(eng->dBigScratch, 0, per * (size_t)B, hs));
+    eng->bigScratchCap = B;
+    return CSIM_OK;
+}
+
 // directory this shared library was loaded from
 std::string ownDirectory()
 {
@@ -150,8 +165,8 @@ int csim_engine_create(const csim_netlist* nl, int32_t device, csim_engine** out
     }
     const csim_ir* ir = nl->cir.view();
     if (ir->n_unknowns <= 0) { setError("circuit has no unknowns"); return CSIM_ERR_EMPTY; }
-    if (ir->n_unknowns > 63) {
-        setError("general kernels cover N <= 63 unknowns");
+    if (ir->n_unknowns > csim::bigMaxUnknowns()) {
+        setError("general kernels cover N <= 320 unknowns");
         return CSIM_ERR_UNSUPPORTED;
     }
     HIPCHK(hipSetDevice(device));
@@ -161,6 +176,7 @@ int csim_engine_create(const csim_netlist* nl, int32_t device, csim_engine** out
     eng->cir = nl->cir;
     eng->cir.view();
     eng->plan = csim::buildAssemblyPlan(*eng->cir.view());
+    eng->big = ir->n_unknowns > 63;
 
     int rc = CSIM_OK;
     const csim::CircuitIR& c = eng->cir;
@@ -190,6 +206,7 @@ void csim_engine_destroy(csim_engine* eng)
     (void)hipSetDevice(eng->device);
     for (void* p : eng->owned) (void)hipFree(p);
     if (eng->dFallback) (void)hipFree(eng->dFallback);
+    if (eng->dBigScratch) (void)hipFree(eng->dBigScratch);
     if (eng->schedLib) dlclose(eng->schedLib);
     delete eng;
 }
@@ -231,6 +248,12 @@ int csim_dc_batch_dev(csim_engine* eng, const double* d_params, int32_t B, doubl
     }
     if (B == 0) return CSIM_OK;
     HIPCHK(hipSetDevice(eng->device));
+    if (eng->big) {
+        const int rc = ensureBigScratch(eng, B, static_cast<hipStream_t>(stream));
+        if (rc) return rc;
+        HIPCHK(csim::launchDcBig(eng->gpDc, d_params, B, eng->dBigScratch, d_x, d_iters, d_status, static_cast<hipStream_t>(stream)));
+        return CSIM_OK;
+    }
     HIPCHK(csim::launchDcGeneral(eng->gpDc, d_params, B, d_x, d_iters, d_status, static_cast<hipStream_t>(stream)));
     return CSIM_OK;
 }
@@ -272,6 +295,14 @@ int csim_tran_batch_dev(csim_engine* eng, const double* d_params, int32_t B, dou
                                          eng->dFallback, stream, eng->schedVariant);
         if (lrc != 0) { setError(std::string("scheduled kernel launch: ") + hipGetErrorString((hipError_t)lrc)); return CSIM_ERR_HIP; }
         only = eng->dFallback;      // ... and re-run below by the general kernel (blocks of unmarked instances exit at once)
+    }
+    if (eng->big) {
+        const int rc = ensureBigScratch(eng, B, hs);
+        if (rc) return rc;
+        HIPCHK(csim::launchTranBig(eng->gpTran, d_params, B, tstep, step_first, n_steps, dProbe, np, os, d_wave, d_x,
+                                   reinterpret_cast<long long*>(d_iters), d_status, d_step_iters, only,
+                                   eng->dBigScratch, nullptr, hs));
+        return CSIM_OK;
     }
     HIPCHK(csim::launchTranGeneral(eng->gpTran, d_params, B, tstep, step_first, n_steps, dProbe, np, os, d_wave, d_x,
                                    reinterpret_cast<long long*>(d_iters), d_status, d_step_iters, only, hs));
@@ -461,9 +492,17 @@ int csim_record_pivot_schedule(csim_engine* eng, const double* d_params, int32_t
     HIPCHK(hipMemset(dOnly.p, 0, (size_t)B));
     const unsigned char one = 1;
     HIPCHK(hipMemcpy(dOnly.as<unsigned char>() + instance, &one, 1, hipMemcpyHostToDevice));
-    HIPCHK(csim::launchTranGeneral(eng->gpTran, d_params, B, tstep, 0, n_steps, nullptr, 0, 1, nullptr, dX.as<double>(),
-                                   dIt.as<long long>(), dSt.as<uint32_t>(), nullptr, dOnly.as<uint8_t>(), nullptr,
-                                   dLog.as<int32_t>(), instance));
+    if (eng->big) {
+        rc = ensureBigScratch(eng, B, nullptr);
+        if (rc) return rc;
+        HIPCHK(csim::launchTranBig(eng->gpTran, d_params, B, tstep, 0, n_steps, nullptr, 0, 1, nullptr, dX.as<double>(),
+                                   dIt.as<long long>(), dSt.as<uint32_t>(), nullptr, dOnly.as<uint8_t>(),
+                                   eng->dBigScratch, nullptr, nullptr, dLog.as<int32_t>(), instance));
+    } else {
+        HIPCHK(csim::launchTranGeneral(eng->gpTran, d_params, B, tstep, 0, n_steps, nullptr, 0, 1, nullptr, dX.as<double>(),
+                                       dIt.as<long long>(), dSt.as<uint32_t>(), nullptr, dOnly.as<uint8_t>(), nullptr,
+                                       dLog.as<int32_t>(), instance));
+    }
     HIPCHK(hipDeviceSynchronize());
     std::vector<int32_t> log((size_t)N + 2);
     HIPCHK(hipMemcpy(log.data(), dLog.p, sizeof(int32_t) * log.size(), hipMemcpyDeviceToHost));

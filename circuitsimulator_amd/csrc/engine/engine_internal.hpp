@@ -36,6 +36,11 @@ struct csim_engine {
     unsigned char* dFallback = nullptr;    // per-instance "re-run with the general kernel" mask
     int fallbackCap = 0;
 
+    // large circuits (N > 63): dense scratch matrices in global memory, one per instance
+    bool big = false;
+    double* dBigScratch = nullptr;
+    int bigScratchCap = 0;                 // instances
+
     // probe list of the most recent transient call
     int32_t* dProbe = nullptr;
     std::vector<int32_t> probeCache;

@@ -22,6 +22,17 @@ hipError_t launchLuFactor(int n, int B, const double* dA, double* dLU, int32_t* 
                           double eps, hipStream_t stream);
 size_t generalLdsBytes(const GenPlan& pl);
 
+// wave-per-instance kernels for 64 <= N <= 320 (kernels_big.hip)
+size_t bigScratchBytesPerInstance(const GenPlan& pl);
+int bigMaxUnknowns();
+hipError_t launchDcBig(const GenPlan& pl, const double* dParams, int B, double* dScratch, double* dX,
+                       int32_t* dIters, uint32_t* dStatus, hipStream_t stream);
+hipError_t launchTranBig(const GenPlan& pl, const double* dParams, int B, double dt, long long stepFirst,
+                         long long nSteps, const int32_t* dProbeEq, int nProbe, int outStride, double* dWave,
+                         double* dX, long long* dIters, uint32_t* dStatus, int32_t* dStepIters,
+                         const uint8_t* dOnly, double* dScratch, const int32_t* dSlotOf, hipStream_t stream,
+                         int32_t* dPivLog = nullptr, int pivInstance = -1);
+
 // Monte-Carlo parameter table (mc.hip)
 hipError_t launchMcParams(int P, int B, long long bFirst, uint64_t seed, double sigma,
                           const int32_t* dKind, const double* dNominal, const double* dMu,
