@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--tsteps", type=int, default=200, help="time steps per bench step (launch)")
     ap.add_argument("--netlist", default=os.path.join(HERE, "tests", "golden", "dbmixer.sp"))
+    ap.add_argument("--ladder", type=int, default=0,
+                    help="use the synthetic RC ladder with this many nodes instead of --netlist (configs[3]: 256)")
+    ap.add_argument("--no-jit", action="store_true", help="do not JIT-specialise a netlist without a prebuilt kernel")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--sigma", type=float, default=0.05)
     ap.add_argument("--kernel", default="auto", choices=["auto", "general", "scheduled"])
@@ -101,7 +104,11 @@ def main():
 
     # ---- netlist: rank 0 reads, RCCL broadcast, every rank parses ------------
     t0 = time.perf_counter()
-    text = open(args.netlist).read() if rank == 0 else ""
+    if args.ladder:
+        from circuitsimulator_amd.workloads import rc_ladder_netlist
+        text = rc_ladder_netlist(args.ladder) if rank == 0 else ""
+    else:
+        text = open(args.netlist).read() if rank == 0 else ""
     text = shard.broadcast_netlist_text(text, src=0, device=dev)
     torch.cuda.synchronize()
     bcast_ms = (time.perf_counter() - t0) * 1e3
@@ -114,6 +121,11 @@ def main():
 
     # ---- per-rank shard of the global batch, regenerated from (seed, b, slot)
     params = eng.mc_params(args.seed, args.sigma, rank * B, B)
+    if eng.tran_kernel == "general" and args.kernel != "general" and not args.no_jit:
+        try:                                  # setup, untimed: plan + generate + hipcc + load
+            eng.jit_scheduled(params, plan_steps=20)
+        except Exception as e:                # no hipcc on the box, circuit too large, ...: stay general
+            print("bench.py: JIT specialisation unavailable (%s); using the general kernel" % e, file=sys.stderr)
     x, dc_it, status = eng.dc(params)
     iters = torch.zeros(B, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
@@ -201,9 +213,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "tests/dbmixer.sp transient (N=%d unknowns), batch=%d MC-perturbed instances per GPU "
+                "workload": "%s transient (N=%d unknowns), batch=%d MC-perturbed instances per GPU "
                             "(sigma=%g, seed=%d), %d time steps of %.3g s per bench step"
-                            % (N, B, args.sigma, args.seed, S, tstep),
+                            % ("synthetic RC ladder" if args.ladder else "tests/" + os.path.basename(args.netlist),
+                               N, B, args.sigma, args.seed, S, tstep),
                 "batch_per_gpu": B,
                 "time_steps_per_step": S,
                 "kernel": eng.tran_kernel,

@@ -674,9 +674,11 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "    r = fma(fma(-a, r, 1.0), r, r);\n"
         << "    return r;\n}\n\n";
 
+    // a variant is emitted only if its LDS image fits one CU (163 840 B)
     auto emitVariant = [&](const VariantOptions& opt, CodegenStats* st) {
         std::ostringstream k;
         const int ldsDoubles = emitKernel(k, ir, ap, sch, opt, st);
+        if (ldsDoubles * 512 > 160 * 1024) return -1;
         std::string text = k.str();
         const std::string token = "@LDS_DOUBLES@";
         const std::size_t at = text.find(token);
@@ -684,12 +686,14 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         src << text;
         return ldsDoubles;
     };
-    // lean: 40 KB of LDS per wave (4 waves per CU): x, then finished U rows up to the budget
+    // lean: 40 KB of LDS per wave (4 waves per CU): x, then finished U rows up to the budget;
+    // for N > 80 the iterate alone exceeds that and the kernel runs fewer waves per CU
     const int leanBudget = 80 - N;
     const int ldsLean = emitVariant({"csim_tran_sched_kernel", false, false, leanBudget > 0 ? leanBudget : 0}, statsOut);
+    if (ldsLean < 0) return std::string();          // the iterate does not fit LDS: no scheduled kernel
     // rich: same residency, every finished U row parked (more LDS per wave: fewer waves per CU)
-    int ldsRich = emitVariant({"csim_tran_sched_kernel_rich", false, false, -1}, nullptr);
-    const bool haveRich = ldsRich * 512 <= 160 * 1024;      // must fit one CU's LDS
+    const int ldsRich = emitVariant({"csim_tran_sched_kernel_rich", false, false, -1}, nullptr);
+    const bool haveRich = ldsRich >= 0;
     std::vector<int> sweep;
     if (const char* sw = std::getenv("CSIM_CG_SWEEP")) {      // tuning aid: "0,8,16,24,32" park budgets
         std::string t(sw);
@@ -724,14 +728,16 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     for (std::size_t k = 0; k < sweep.size(); ++k)
         src << "    if (variant == " << (10 + k) << ") { hipLaunchKernelGGL(csim_tran_sched_kernel_sweep" << k
             << ", dim3(waves), dim3(64), 0, (hipStream_t)stream, params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status, stepIters, fallback); return (int)hipGetLastError(); }\n";
-    src << "    if (rich)\n"
-        << "        hipLaunchKernelGGL(csim_tran_sched_kernel_rich, dim3(waves), dim3(64), 0, (hipStream_t)stream,\n"
-        << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
-        << "                           stepIters, fallback);\n"
-        << "    else\n"
-        << "        hipLaunchKernelGGL(csim_tran_sched_kernel, dim3(waves), dim3(64), 0, (hipStream_t)stream,\n"
-        << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
-        << "                           stepIters, fallback);\n"
+    if (haveRich)
+        src << "    if (rich) {\n"
+            << "        hipLaunchKernelGGL(csim_tran_sched_kernel_rich, dim3(waves), dim3(64), 0, (hipStream_t)stream,\n"
+            << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
+            << "                           stepIters, fallback);\n"
+            << "        return (int)hipGetLastError();\n    }\n";
+    src << "    (void)rich;\n"
+        << "    hipLaunchKernelGGL(csim_tran_sched_kernel, dim3(waves), dim3(64), 0, (hipStream_t)stream,\n"
+        << "                       params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
+        << "                       stepIters, fallback);\n"
         << "    return (int)hipGetLastError();\n}\n";
     return src.str();
 }

@@ -537,6 +537,7 @@ int csim_engine_jit_scheduled(csim_engine* eng, const double* d_params, int32_t 
     if (!handle) {
         if (std::system(("mkdir -p '" + dir + "'").c_str()) != 0) { setError("cannot create " + dir); return CSIM_ERR_IO; }
         const std::string src = csim::generateTranKernelSource(*ir, eng->plan, sch, "jit", nullptr);
+        if (src.empty()) { setError("circuit too large for a scheduled kernel (iterate does not fit LDS)"); return CSIM_ERR_UNSUPPORTED; }
         FILE* f = std::fopen(hip.c_str(), "w");
         if (!f) { setError("cannot write " + hip); return CSIM_ERR_IO; }
         std::fwrite(src.data(), 1, src.size(), f);

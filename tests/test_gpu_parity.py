@@ -295,7 +295,7 @@ def test_error_codes(engines):
     with pytest.raises(CsimError) as e:
         Engine(nl, 99)
     assert e.value.code == capi.CSIM_ERR_NO_DEVICE
-    big = "V1 n0 0 1\n" + "".join("R%d n%d n%d 1\n" % (i, i, i + 1) for i in range(70)) + "R99 n70 0 1\n"
+    big = "V1 n0 0 1\n" + "".join("R%d n%d n%d 1\n" % (i, i, i + 1) for i in range(330)) + "R999 n330 0 1\n"
     with pytest.raises(CsimError) as e:
         Engine(Netlist.from_text(big), 0)
     assert e.value.code == capi.CSIM_ERR_UNSUPPORTED
@@ -491,3 +491,88 @@ def test_jit_scheduled_kernel_for_a_new_netlist(torch_mod, tmp_path, monkeypatch
     eng2 = Engine(nl, 0)
     eng2.jit_scheduled(params, plan_steps=300)
     assert eng2.tran_kernel == "scheduled"
+
+
+# ------------------------------- BASELINE configs[3]: RC ladder, N = 257 unknowns
+
+@pytest.fixture(scope="module")
+def ladder(torch_mod):
+    from circuitsimulator_amd import Engine, Netlist
+    from circuitsimulator_amd.workloads import rc_ladder_netlist
+    nl = Netlist.from_text(rc_ladder_netlist(256))
+    assert (nl.n_unknowns, nl.n_elems, nl.n_params) == (257, 511, 516)
+    return nl, Engine(nl, 0)
+
+
+def test_rc_ladder_large_n_general_kernels(ladder, torch_mod):
+    """N = 257 > 63: the bit-guided global-scratch kernels.  Linear circuit -> direct DC (one LU,
+    no gmin); 100 transient steps = 1 687 NR iterations (SURVEY.md 8d #4 fingerprint)."""
+    nl, eng = ladder
+    eng.set_kernel("general")
+    B = 3
+    params = eng.mc_params(12345, 0.05, 0, B)
+    r = _run_tran(torch_mod, eng, params, 100, nl.tstep, probes=[0, 128, 255, 256], stride=10, want_step_iters=True)
+    eng.set_kernel("auto")
+    assert list(r["dc_iters"]) == [1, 1, 1]
+    assert r["iters"][0] == 1687
+    ph = params.cpu().numpy()
+    for b in (0, 2):
+        xo, ito, sto = _orc().dc(nl.ir_ptr, 257, ph, b)
+        assert rel_err(r["x_dc"][:, b], xo, 256).max() < TOL
+        o = _orc().tran(nl.ir_ptr, 257, ph, b, nl.tstep, nl.tstop, want_step_iters=True)
+        assert r["iters"][b] == o["iters"] and np.array_equal(r["step_iters"][:, b], o["step_iters"])
+        assert r["status"][b] == o["status"]
+        assert rel_err(r["x"][:, b], o["x_final"], 256).max() < TOL
+        ref = o["rows"][::10, 1:][:, [0, 128, 255, 256]]
+        assert np.abs(r["wave"][:, :, b] - ref).max() <= TOL * max(np.abs(ref).max(), 1e-6)
+
+
+def test_rc_ladder_scheduled_kernel_at_config_batch(ladder, torch_mod, tmp_path, monkeypatch):
+    """configs[3] per-GPU share: B = 8192 instances of the N = 257 ladder, JIT-specialised kernel."""
+    import shutil, os
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available for the JIT")
+    monkeypatch.setenv("CSIM_JIT_DIR", str(tmp_path / "jit"))
+    nl, eng = ladder
+    B = 8192
+    params = eng.mc_params(12345, 0.05, 0, B)
+    eng.jit_scheduled(params, plan_steps=5)
+    assert eng.tran_kernel == "scheduled"
+    r = _run_tran(torch_mod, eng, params, 100, nl.tstep, chunks=[40, 60])
+    assert not (r["status"] & 0x27).any()
+    assert r["iters"][0] == 1687
+    one = _run_tran(torch_mod, eng, params[:, :1].contiguous(), 100, nl.tstep)
+    assert np.array_equal(one["x"][:, 0], r["x"][:, 0])                       # batch invariance
+    ph = params[:, [0, 1, B - 1]].cpu().numpy()
+    for j, b in enumerate((0, 1, B - 1)):
+        o = _orc().tran(nl.ir_ptr, 257, ph, j, nl.tstep, nl.tstop, want_rows=False)
+        assert r["iters"][b] == o["iters"]
+        assert rel_err(r["x"][:, b], o["x_final"], 256).max() < TOL
+
+
+def test_mid_size_nonlinear_circuit_big_kernels(torch_mod):
+    """A nonlinear circuit with 63 < N <= 320: Newton DC ramp + transient on the large-N kernels."""
+    from circuitsimulator_amd import Engine, Netlist
+    stages = 20
+    txt = ["VDD vdd 0 DC 2.5", "Vin n0 0 SIN 1.25 1.0 100e6 0"]
+    for k in range(stages):
+        txt += ["M%da n%d g%d vdd p 40e-6 0.5e-6 1" % (k, k + 1, k), "M%db n%d g%d 0 n 20e-6 0.5e-6 2" % (k, k + 1, k),
+                "R%d n%d g%d 200" % (k, k, k), "C%d n%d 0 5e-15" % (k, k + 1), "L%d n%d t%d 1e-10" % (k, k + 1, k),
+                "R%dt t%d 0 1e5" % (k, k)]
+    txt += [".MODEL 1 VT -0.6 MU 2e-2 COX 2e-3 LAMBDA 0.04 CJ0 2e-14", ".MODEL 2 VT 0.55 MU 6e-2 COX 2e-3 LAMBDA 0.04 CJ0 2e-14",
+            ".TRAN 5e-12 1e-9"]
+    nl = Netlist.from_text("\n".join(txt) + "\n")
+    assert 63 < nl.n_unknowns <= 320
+    eng = Engine(nl, 0)
+    B = 2
+    params = eng.mc_params(9, 0.05, 0, B)
+    r = _run_tran(torch_mod, eng, params, 40, nl.tstep, want_step_iters=True)
+    ph = params.cpu().numpy()
+    for b in range(B):
+        xo, ito, sto = _orc().dc(nl.ir_ptr, nl.n_unknowns, ph, b)
+        assert r["dc_iters"][b] == ito
+        assert rel_err(r["x_dc"][:, b], xo, nl.n_node_eq).max() < TOL
+        o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstep * 40, want_rows=False, want_step_iters=True)
+        assert r["iters"][b] == o["iters"] and np.array_equal(r["step_iters"][:, b], o["step_iters"])
+        assert (r["status"][b] & NOFB) == o["status"]
+        assert rel_err(r["x"][:, b], o["x_final"], nl.n_node_eq).max() < TOL
