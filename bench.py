@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--sigma", type=float, default=0.05)
     ap.add_argument("--kernel", default="auto", choices=["auto", "general", "scheduled"])
-    ap.add_argument("--cpu-iters", type=float, default=1.2e6, help="approx. NR iterations of the CPU sample")
+    ap.add_argument("--cpu-iters", type=float, default=3.0e6, help="approx. NR iterations of the CPU sample (~15 s)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--large-batch", type=int, default=65536,
                     help="also time this many instances per GPU (one wave per SIMD needs >= 65536); 0 = skip")

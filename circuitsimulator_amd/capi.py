@@ -49,6 +49,8 @@ PROTOTYPES = {
     "csim_netlist_probe_eq": (C.c_int, [_vp, _i32]),
     "csim_netlist_num_dc_sweeps": (C.c_int, [_vp]),
     "csim_netlist_dc_sweep": (C.c_int, [_vp, _i32, _pi32, _pdbl, _pdbl, _pdbl]),
+    "csim_netlist_dc_sweep_points": (_i64, [_vp, _i32]),
+    "csim_netlist_dc_sweep_params": (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
     "csim_netlist_csv_header": (C.c_int, [_vp, _cp, _i32]),
     "csim_netlist_mc_kinds": (C.c_int, [_vp, _vp]),
     "csim_engine_create": (C.c_int, [_vp, _i32, C.POINTER(_vp)]),

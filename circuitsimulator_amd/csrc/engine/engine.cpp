@@ -3,6 +3,7 @@
 // HIP device csim_engine_create fails (CSIM_ERR_NO_DEVICE).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cmath>
 #include <cstdio>
@@ -538,15 +539,19 @@ int csim_engine_jit_scheduled(csim_engine* eng, const double* d_params, int32_t 
         if (std::system(("mkdir -p '" + dir + "'").c_str()) != 0) { setError("cannot create " + dir); return CSIM_ERR_IO; }
         const std::string src = csim::generateTranKernelSource(*ir, eng->plan, sch, "jit", nullptr);
         if (src.empty()) { setError("circuit too large for a scheduled kernel (iterate does not fit LDS)"); return CSIM_ERR_UNSUPPORTED; }
-        FILE* f = std::fopen(hip.c_str(), "w");
-        if (!f) { setError("cannot write " + hip); return CSIM_ERR_IO; }
+        // several ranks may specialise the same circuit at once: private temporaries, atomic rename
+        const std::string tag = "." + std::to_string((long long)getpid());
+        const std::string hipTmp = hip + tag, libTmp = lib + tag;
+        FILE* f = std::fopen(hipTmp.c_str(), "w");
+        if (!f) { setError("cannot write " + hipTmp); return CSIM_ERR_IO; }
         std::fwrite(src.data(), 1, src.size(), f);
         std::fclose(f);
         const char* ccEnv = std::getenv("CSIM_HIPCC");
         const std::string cc = ccEnv ? ccEnv : "/opt/rocm/bin/hipcc";
-        const std::string cmd = cc + " -O3 -std=c++17 -fPIC --offload-arch=gfx950 -shared '" + hip + "' -o '" + lib +
-                                ".tmp' > '" + log + "' 2>&1 && mv '" + lib + ".tmp' '" + lib + "'";
-        if (std::system(cmd.c_str()) != 0) { setError("hipcc failed, see " + log); return CSIM_ERR_UNSUPPORTED; }
+        const std::string cmd = cc + " -O3 -std=c++17 -fPIC --offload-arch=gfx950 -shared -x hip '" + hipTmp + "' -o '" +
+                                libTmp + "' > '" + log + tag + "' 2>&1 && mv '" + libTmp + "' '" + lib + "' && mv '" +
+                                hipTmp + "' '" + hip + "'";
+        if (std::system(cmd.c_str()) != 0) { setError("hipcc failed, see " + log + tag); return CSIM_ERR_UNSUPPORTED; }
         handle = dlopen(lib.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (!handle) { setError(std::string("dlopen: ") + dlerror()); return CSIM_ERR_IO; }
     }

@@ -3,6 +3,7 @@
 // every caller of the reference performs (src/main.cpp:29,34).
 #include "netlist_internal.hpp"
 
+#include <cmath>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -156,6 +157,48 @@ int csim_netlist_dc_sweep(const csim_netlist* nl, int32_t i, int32_t* src_elem,
     if (start) *start = dc.start;
     if (stop)  *stop = dc.stop;
     if (step)  *step = dc.step;
+    return CSIM_OK;
+}
+
+static int sweepSource(const csim_netlist* nl, int32_t i, int* elem, double* a, double* b, double* st)
+{
+    int32_t e = -1;
+    if (csim_netlist_dc_sweep(nl, i, &e, a, b, st) != CSIM_OK) return CSIM_ERR_ARG;
+    if (e < 0) return CSIM_ERR_ARG;
+    const int kind = nl->cir.kind[static_cast<std::size_t>(e)];
+    if (kind != CSIM_V && kind != CSIM_I) return CSIM_ERR_ARG;
+    *elem = e;
+    return CSIM_OK;
+}
+
+int64_t csim_netlist_dc_sweep_points(const csim_netlist* nl, int32_t i)
+{
+    int e = -1;
+    double a = 0, b = 0, st = 0;
+    if (!nl || sweepSource(nl, i, &e, &a, &b, &st) != CSIM_OK) return 0;
+    if (st == 0.0 || (b - a) / st < 0.0) return 0;
+    return static_cast<int64_t>(std::floor((b - a) / st + 1e-9)) + 1;
+}
+
+int csim_netlist_dc_sweep_params(const csim_netlist* nl, int32_t i, int64_t n_points, double* params, double* values)
+{
+    int e = -1;
+    double a = 0, b = 0, st = 0;
+    if (!nl || !params || n_points < 0 || sweepSource(nl, i, &e, &a, &b, &st) != CSIM_OK) {
+        csim::setError("csim_netlist_dc_sweep_params: bad sweep");
+        return CSIM_ERR_ARG;
+    }
+    const csim::CircuitIR& c = nl->cir;
+    const int P = static_cast<int>(c.nominal.size());
+    const int slot = c.paramSlot[static_cast<std::size_t>(e)];      // SourceSpec::dcValue
+    for (int p = 0; p < P; ++p)
+        for (int64_t j = 0; j < n_points; ++j)
+            params[static_cast<int64_t>(p) * n_points + j] = c.nominal[static_cast<std::size_t>(p)];
+    for (int64_t j = 0; j < n_points; ++j) {
+        const double v = a + static_cast<double>(j) * st;
+        params[static_cast<int64_t>(slot) * n_points + j] = v;
+        if (values) values[j] = v;
+    }
     return CSIM_OK;
 }
 

@@ -82,6 +82,16 @@ class Netlist:
             out.append((e.value, a.value, b.value, s.value))
         return out
 
+    def dc_sweep_table(self, i=0):
+        """(.DC card i) -> (swept values [n], params [P][n]); every point is one DC instance."""
+        L = capi.lib()
+        n = L.csim_netlist_dc_sweep_points(self._h, i)
+        params = np.zeros((self.n_params, n), dtype=np.float64)
+        values = np.zeros(n, dtype=np.float64)
+        if n > 0:
+            capi.check(L.csim_netlist_dc_sweep_params(self._h, i, n, params.ctypes.data, values.ctypes.data))
+        return values, params
+
     def mc_params_host(self, seed, sigma, b_first, B):
         """Host mirror of the device generator: numpy [P][B] (slot-major)."""
         out = np.zeros((self.n_params, B), dtype=np.float64)
@@ -155,6 +165,12 @@ class Engine:
         capi.check(capi.lib().csim_dc_batch_dev(self._h, params.data_ptr(), B, x.data_ptr(), it.data_ptr(),
                                                 st.data_ptr(), self._stream()))
         return x, it, st
+
+    def dc_sweep(self, i=0):
+        """Execute .DC card i of the netlist as one batch: -> (values, x [N][n], iters, status)."""
+        values, table = self.netlist.dc_sweep_table(i)
+        x, it, st = self.dc(self.upload_params(table))
+        return values, x, it, st
 
     def tran(self, params, x, tstep, step_first, n_steps, iters, status, probes=None, out_stride=1,
              wave=None, step_iters=None):

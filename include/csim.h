@@ -83,6 +83,15 @@ int  csim_netlist_probe_eq(const csim_netlist* nl, int32_t i);
 int  csim_netlist_num_dc_sweeps(const csim_netlist* nl);
 int  csim_netlist_dc_sweep(const csim_netlist* nl, int32_t i, int32_t* src_elem,
                            double* start, double* stop, double* step);
+/* .DC sweep as a batch axis (the reference parses the card and never executes it,
+ * src/parser.cpp:476-495; src/main.cpp never reads sim.dcSweeps): sweep point j is the
+ * nominal circuit with the swept source's dcValue replaced by start + j*step.
+ * points = floor((stop-start)/step + 1e-9) + 1, 0 for step == 0, a step of the wrong sign
+ * or a card whose source is not a V/I element.                                        */
+int64_t csim_netlist_dc_sweep_points(const csim_netlist* nl, int32_t i);
+/* parameter table [P][n_points] (slot-major) + the swept values [n_points]              */
+int  csim_netlist_dc_sweep_params(const csim_netlist* nl, int32_t i, int64_t n_points,
+                                  double* params, double* values);
 /* header line of the reference's transient CSV (src/tanalisis.cpp:191-206):
  * "time,V(<node>)...,I(<elem>)..."; returns the length needed (excl. NUL) */
 int  csim_netlist_csv_header(const csim_netlist* nl, char* buf, int32_t cap);

@@ -130,3 +130,18 @@ def test_num_steps_rule():
     assert L.csim_tran_num_rows(1e-9, 10e-9, 0.0, 1) == 11
     assert L.csim_tran_num_rows(1e-9, 10e-9, 2e-9, 1) == 9      # rows with t < tstart suppressed
     assert L.csim_tran_num_rows(1e-9, 10e-9, 0.0, 5) == 3
+
+
+def test_dc_sweep_table():
+    nl = Netlist.from_text("V1 in 0 DC 1\nR1 in out 1k\nR2 out 0 1k\nI1 0 out 1m\n.dc V1 0 2 0.5\n.dc I1 1m 0 -0.25m\n"
+                           ".dc R1 0 1 1\n.dc V1 0 1 0\n.dc V1 0 1 -1\n")
+    assert nl.dc_sweeps()[0] == (0, 0.0, 2.0, 0.5)
+    v, t = nl.dc_sweep_table(0)
+    assert list(v) == [0.0, 0.5, 1.0, 1.5, 2.0] and t.shape == (nl.n_params, 5)
+    assert list(t[0]) == [0.0, 0.5, 1.0, 1.5, 2.0]              # V1's dcValue slot
+    assert np.array_equal(t[1:], np.repeat(nl.nominal_params[1:, None], 5, axis=1))
+    v, t = nl.dc_sweep_table(1)                                 # descending sweep of a current source
+    assert len(v) == 5 and v[0] == 1e-3 and abs(v[-1]) < 1e-18
+    assert nl.dc_sweep_table(2)[0].size == 0                    # not a source
+    assert nl.dc_sweep_table(3)[0].size == 0                    # zero step
+    assert nl.dc_sweep_table(4)[0].size == 0                    # step of the wrong sign
