@@ -243,10 +243,10 @@ def main():
         if world == 1 and not args.no_cpu:
             # CPU baseline: the oracle (port of the reference algorithm), 1 thread,
             # on the first instances of the same parameter table
-            ph = params[:, :64].cpu().numpy()
+            ph = params[:, :256].cpu().numpy()
             s_cpu = min(S * args.steps, 2000)
             est_per_inst = 10.0 * s_cpu
-            n_cpu = int(max(1, min(64, round(args.cpu_iters / est_per_inst))))
+            n_cpu = int(max(1, min(ph.shape[1], round(args.cpu_iters / est_per_inst))))
             ci, cdt = cpu_baseline(nl, ph, n_cpu, tstep, s_cpu)
             rec["cpu_baseline"] = {
                 "value": ci / cdt,

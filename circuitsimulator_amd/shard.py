@@ -36,7 +36,9 @@ def init_process_group(backend=None):
     import torch
     import torch.distributed as dist
     rank, local_rank, world = dist_env()
-    if world <= 1 or dist.is_initialized():
+    # a single rank needs no process group; CSIM_FORCE_DIST=1 creates one anyway so that the
+    # RCCL calls can be rehearsed on a one-GPU box
+    if dist.is_initialized() or (world <= 1 and os.environ.get("CSIM_FORCE_DIST") != "1"):
         return rank, local_rank, world
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -44,7 +46,8 @@ def init_process_group(backend=None):
     os.environ.setdefault("MASTER_PORT", "29500")
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
-    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+    dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 
 
@@ -57,7 +60,7 @@ def broadcast_netlist_text(text, src=0, device=None):
     """Rank `src` sends the netlist text; every rank returns the same str."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return text
     dev = _dev(device)
     rank = dist.get_rank()
@@ -83,7 +86,7 @@ def all_gather_instances(local, total, device=None):
     """
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local
     world = dist.get_world_size()
     sizes = [shard_range(total, r, world) for r in range(world)]
@@ -100,7 +103,7 @@ def all_reduce_sum(value, device=None):
     """Sum of a python int/float (or tensor) over all ranks."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return value
     t = value if torch.is_tensor(value) else torch.tensor([value], dtype=torch.float64, device=_dev(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -110,7 +113,7 @@ def all_reduce_sum(value, device=None):
 def all_reduce_max(value, device=None):
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return value
     t = torch.tensor([value], dtype=torch.float64, device=_dev(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -119,5 +122,5 @@ def all_reduce_max(value, device=None):
 
 def barrier():
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
