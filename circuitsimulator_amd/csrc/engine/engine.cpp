@@ -89,11 +89,11 @@ int ensureProbes(csim_engine* eng, const int32_t* probe_eq, int n_probe, const i
     const int N = eng->plan.N;
     for (int i = 0; i < n_probe; ++i)
         if (probe_eq[i] < 0 || probe_eq[i] >= N) { setError("probe equation index out of range"); return CSIM_ERR_ARG; }
-    if (n_probe > 64) { setError("at most 64 probes per launch"); return CSIM_ERR_UNSUPPORTED; }
+    if (n_probe > 1024) { setError("at most 1024 probes per launch"); return CSIM_ERR_UNSUPPORTED; }
     std::vector<int32_t> want(probe_eq, probe_eq + n_probe);
     if (want != eng->probeCache) {
         if (!eng->dProbe) {
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dProbe), sizeof(int32_t) * 64));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dProbe), sizeof(int32_t) * 1024));
             eng->owned.push_back(eng->dProbe);
         }
         HIPCHK(hipMemcpy(eng->dProbe, want.data(), sizeof(int32_t) * want.size(), hipMemcpyHostToDevice));

@@ -385,7 +385,8 @@ k_tran_big(GenPlan pl, const double* __restrict__ params, int B, double dt, long
     if (lane == 0) L.T[pl.termGmin] = K.tran_gmin;
     wave_sync();
 
-    if (stepFirst == 0 && wave && lane < nProbe) wave[((int64_t)0 * nProbe + lane) * B + b] = L.xs[probeEq[lane]];
+    if (stepFirst == 0 && wave)
+        for (int q = lane; q < nProbe; q += 64) wave[((int64_t)0 * nProbe + q) * B + b] = L.xs[probeEq[q]];
 
     unsigned st = (status[b] & CSIM_ST_TRAN_NONFINITE);
     if (only) st |= CSIM_ST_SCHED_FALLBACK;
@@ -431,8 +432,9 @@ k_tran_big(GenPlan pl, const double* __restrict__ params, int B, double dt, long
         if (aborted) break;
         for (int i = lane; i < N; i += 64) L.xp[i] = L.xs[i];
         wave_sync();
-        if (wave && (gstep % outStride) == 0 && lane < nProbe)
-            wave[((gstep / outStride) * nProbe + lane) * (int64_t)B + b] = L.xs[probeEq[lane]];
+        if (wave && (gstep % outStride) == 0)
+            for (int q = lane; q < nProbe; q += 64)
+                wave[((gstep / outStride) * nProbe + q) * (int64_t)B + b] = L.xs[probeEq[q]];
     }
 
     for (int i = lane; i < N; i += 64) xio[(int64_t)i * B + b] = L.xs[i];

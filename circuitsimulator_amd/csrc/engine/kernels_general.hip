@@ -158,8 +158,8 @@ k_tran_general(GenPlan pl, const double* __restrict__ params, int B, double dt,
     if (lane == 0) T[pl.termGmin] = K.tran_gmin;
     wave_sync();
 
-    if (stepFirst == 0 && wave && lane < nProbe)    // t = 0 row (:250)
-        wave[((int64_t)0 * nProbe + lane) * B + b] = xs[probeEq[lane]];
+    if (stepFirst == 0 && wave)                     // t = 0 row (:250)
+        for (int q = lane; q < nProbe; q += 64) wave[((int64_t)0 * nProbe + q) * B + b] = xs[probeEq[q]];
 
     unsigned st = (status[b] & CSIM_ST_TRAN_NONFINITE);
     if (only) st |= CSIM_ST_SCHED_FALLBACK;
@@ -196,8 +196,9 @@ k_tran_general(GenPlan pl, const double* __restrict__ params, int B, double dt,
         if (aborted) break;
         if (lane < N) xp[lane] = xs[lane];                              // :381-417
         wave_sync();
-        if (wave && (gstep % outStride) == 0 && lane < nProbe)          // :419
-            wave[((gstep / outStride) * nProbe + lane) * (int64_t)B + b] = xs[probeEq[lane]];
+        if (wave && (gstep % outStride) == 0)                           // :419
+            for (int q = lane; q < nProbe; q += 64)
+                wave[((gstep / outStride) * nProbe + q) * (int64_t)B + b] = xs[probeEq[q]];
     }
 
     if (lane < N) xio[(int64_t)lane * B + b] = xs[lane];

@@ -527,6 +527,17 @@ def test_rc_ladder_large_n_general_kernels(ladder, torch_mod):
         assert np.abs(r["wave"][:, :, b] - ref).max() <= TOL * max(np.abs(ref).max(), 1e-6)
 
 
+def test_rc_ladder_full_waveform_host_api(ladder):
+    """All 257 unknowns probed (more probes than lanes) through the instance-major host API."""
+    nl, eng = ladder
+    eng.set_kernel("general")
+    wave, xf, it, st = eng.tran_host(B=1, tstop=20e-9, probes=list(range(257)))
+    eng.set_kernel("auto")
+    o = _orc().tran(nl.ir_ptr, 257, nl.nominal_params, 0, nl.tstep, 20e-9)
+    assert wave.shape == (1, 21, 257) and it[0] == o["iters"]
+    assert rel_err(wave[0], o["rows"][:, 1:], 256).max() < TOL
+
+
 def test_rc_ladder_scheduled_kernel_at_config_batch(ladder, torch_mod, tmp_path, monkeypatch):
     """configs[3] per-GPU share: B = 8192 instances of the N = 257 ladder, JIT-specialised kernel."""
     import shutil, os
