@@ -2,6 +2,7 @@
 // substitution over {zero, exact constant, run-time value}; emits HIP source.
 #include "codegen.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -327,7 +328,8 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         << "    const int b = blockIdx.x * 64 + threadIdx.x;\n"
         << "    const bool inb = b < B;\n"
         << "    const long long bb = inb ? b : B - 1;      // out-of-range lanes shadow the last instance, never store\n"
-        << "    const long long SB = B;\n";
+        << "    const long long SB = B;\n"
+        << "    const bool splitFlag = outStride < 0;      // never true (the engine rejects it); opaque to the compiler\n";
 
     // ---- parameters
     for (int p = 0; p < ir.n_params; ++p) {
@@ -504,14 +506,18 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
     g.out << g.ind << "bool pv = false;     // a pivot check failed in this iteration\n";
     std::vector<AV> rinv(static_cast<std::size_t>(N));      // 1 / U(k,k)
     int parked = 0;
+    const int splitEvery = std::getenv("CSIM_CG_SPLIT") ? std::max(1, std::atoi(std::getenv("CSIM_CG_SPLIT"))) : 0;
     for (int k = 0; k < N; ++k) {
         const int p = sch.pivotPos[static_cast<std::size_t>(k)];
         const AV ap_ = at(p, k);
         g.out << g.ind << "// column " << k << ": pivot row position " << p << "\n";
-        // keep the machine scheduler from pulling later columns' independent work
-        // (assembly sums, MOS terms) to the top of this 3000-instruction block: that
-        // is what inflates the live set to >400 doubles
-        if (std::getenv("CSIM_CG_NOBARRIER") == nullptr) g.out << g.ind << "__builtin_amdgcn_sched_barrier(0);\n";
+        // Tuning knob (off by default): a basic-block boundary every CSIM_CG_SPLIT columns through a
+        // scalar branch on an opaque, never-true flag.  hipcc schedules each basic block for ILP and
+        // inflates the live set of this 3000-instruction body; the short-circuit "pv = pv || ..."
+        // chains below already split it (turning them into branch-free "|=" was measured 37 %
+        // slower: 6.5e8 -> 4.1e8), extra boundaries were measured neutral (6.3e8).
+        if (splitEvery > 0 && (k % splitEvery) == 0)
+            g.out << g.ind << "if (splitFlag) asm volatile(\"s_nop 0\");\n";
         // the reference picks the FIRST row attaining the column maximum (solver.hpp:48-56)
         // and fails below 1e-15 (:58-61)
         if (ap_.isZero()) {
