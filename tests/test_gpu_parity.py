@@ -609,3 +609,28 @@ def test_dc_sweep_axis(torch_mod):
     assert np.allclose(x[nl.eq_names.index("101")], values + 1.5, rtol=0, atol=1e-8)
     out = x[nl.eq_names.index("118")]
     assert out[0] < 0.1 and out[-1] > 2.9          # non-inverting buffer: low in -> low out, high in -> high out
+
+
+def test_cpp_batch_api(engines):
+    """csim::BatchEngine (api/analysis.hpp) from C++: Monte-Carlo table, batched DC, batched transient."""
+    import json
+    import os
+    import subprocess
+    from conftest import ROOT
+    nl, eng = engines["dbmixer"]
+    exe = os.path.join(ROOT, "circuitsimulator_amd", "csim_batch_demo")
+    B, steps = 5, 300
+    p = subprocess.run([exe, netlist_path("dbmixer.sp"), str(B), str(steps)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    recs = [json.loads(l) for l in p.stdout.strip().splitlines()]
+    assert len(recs) == B
+    tab = nl.mc_params_host(12345, 0.05, 0, B)
+    for r in recs:
+        b = r["b"]
+        xo, ito, sto = _orc().dc(nl.ir_ptr, nl.n_unknowns, tab, b)
+        assert r["dc_iters"] == ito and r["dc_status"] == sto
+        o = _orc().tran(nl.ir_ptr, nl.n_unknowns, tab, b, nl.tstep, nl.tstep * steps, want_rows=False)
+        assert r["tran_iters"] == o["iters"] and (r["status"] & NOFB) == (o["status"] | sto)
+        assert r["rows"] == 2                                   # out_stride = n_steps: t = 0 and the last row
+        assert rel_err(np.array(r["x_final"]), o["x_final"], nl.n_node_eq).max() < TOL
+        assert abs(r["wave_last"] - o["x_final"][-1]) <= TOL * max(abs(o["x_final"][-1]), 1e-6)
