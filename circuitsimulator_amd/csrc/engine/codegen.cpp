@@ -49,6 +49,54 @@ std::string PivotSchedule::str() const
     return o.str();
 }
 
+bool ScheduleSet::parse(const std::string& text, int N, ScheduleSet& out)
+{
+    out.alts.clear();
+    std::size_t i = 0;
+    while (i <= text.size()) {
+        std::size_t e = text.find('\n', i);
+        if (e == std::string::npos) e = text.size();
+        std::string line = text.substr(i, e - i);
+        i = e + 1;
+        const std::size_t hashAt = line.find('#');                  // comment to end of line
+        if (hashAt != std::string::npos) line = line.substr(0, hashAt);
+        std::size_t j = 0;
+        while (j <= line.size()) {                                   // ';' separates schedules on one line
+            std::size_t f = line.find(';', j);
+            if (f == std::string::npos) f = line.size();
+            std::string body = line.substr(j, f - j);
+            j = f + 1;
+            bool blank = true, dash = false;
+            for (char ch : body) { blank = blank && (ch == ' ' || ch == '\t' || ch == '\r' || ch == ','); dash = dash || ch == '-'; }
+            if (blank) continue;
+            if (dash) for (char& ch : body) if (ch == '-') ch = ' ';  // "-" = no swaps
+            PivotSchedule one;
+            if (!PivotSchedule::parse(body, N, one)) return false;
+            bool dup = false;
+            for (const PivotSchedule& a : out.alts) dup = dup || a.pivotPos == one.pivotPos;
+            if (!dup) out.alts.push_back(one);
+        }
+    }
+    return !out.alts.empty();
+}
+
+std::string ScheduleSet::str() const
+{
+    std::string o;
+    for (std::size_t a = 0; a < alts.size(); ++a) o += (a ? " ; " : "") + (alts[a].str().empty() ? std::string("-") : alts[a].str());
+    return o;
+}
+
+uint64_t scheduleHash(const csim_ir& ir, const ScheduleSet& set)
+{
+    uint64_t h = scheduleHash(ir, set.alts.empty() ? PivotSchedule::identity(ir.n_unknowns) : set.alts[0]);
+    for (std::size_t a = 1; a < set.alts.size(); ++a) {
+        h ^= 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        for (int p : set.alts[a].pivotPos) { h ^= static_cast<uint64_t>(p + 1); h *= 1099511628211ull; }
+    }
+    return h;
+}
+
 uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch)
 {
     uint64_t h = 1469598103934665603ull;                 // FNV-1a
@@ -57,7 +105,7 @@ uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch)
         for (std::size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
     };
     auto mixInt = [&](int32_t v) { mixBytes(&v, sizeof v); };
-    mixInt(2);                                            // generator revision
+    mixInt(5);                                            // generator revision
     mixInt(ir.n_unknowns); mixInt(ir.n_node_eq); mixInt(ir.n_branch_eq);
     mixInt(ir.n_elems); mixInt(ir.n_params); mixInt(ir.has_nonlinear);
     for (int e = 0; e < ir.n_elems; ++e) {
@@ -221,7 +269,7 @@ struct VariantOptions {
 };
 
 // emits ONE __global__ kernel; returns the number of LDS doubles per lane it uses
-int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch,
+int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& ap, const ScheduleSet& set,
                const VariantOptions& opt, CodegenStats* statsOut)
 {
     const int N = ir.n_unknowns;
@@ -322,7 +370,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         << "                       long long nSteps, const int* __restrict__ probeEq, int nProbe, int outStride,\n"
         << "                       double* __restrict__ wave, double* __restrict__ xio, long long* __restrict__ iters,\n"
         << "                       unsigned* __restrict__ status, int* __restrict__ stepIters,\n"
-        << "                       unsigned char* __restrict__ fallback)\n{\n"
+        << "                       unsigned char* __restrict__ fallback, int* __restrict__ done)\n{\n"
         << "    __shared__ double lds[@LDS_DOUBLES@ * 64];\n"
         << "    const int lane = threadIdx.x;\n"
         << "    const int b = blockIdx.x * 64 + threadIdx.x;\n"
@@ -368,13 +416,21 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
     src << "    unsigned st = inb ? status[bb] : 0u;\n"
         << "    bool dead = !inb || (st & ST_TRAN_NONFINITE) != 0u;   // the reference would have thrown: stay stopped\n"
         << "    long long itTotal = 0;\n"
-        << "    if (stepFirst == 0 && wave && inb) {\n"
+        << "    // steps of this launch already completed for this instance (hybrid stepping: after a schedule\n"
+        << "    // violation the general kernel advances the instance a few steps and hands it back)\n"
+        << "    long long sdone = (inb && !dead) ? (long long)done[bb] : nSteps;\n"
+        << "    if (stepFirst == 0 && sdone == 0 && wave && inb) {\n"
         << "        for (int q = 0; q < nProbe; ++q) wave[((long long)q) * SB + b] = X(probeEq[q]);\n"
         << "    }\n\n"
-        << "    for (long long s = 1; s <= nSteps; ++s) {\n"
-        << "        if (!__any(!dead && !viol)) break;\n"
+        << "    for (;;) {\n"
+        << "        const bool live = !dead && !viol && sdone < nSteps;\n"
+        << "        if (!__any(live)) break;\n"
+        << "        const long long s = sdone + 1;              // per lane: lanes of a wave may be at different steps\n"
         << "        const long long gstep = stepFirst + s;\n"
-        << "        const double tNow = (double)(int)gstep * dt;\n";
+        << "        const double tNow = (double)(int)gstep * dt;\n"
+        << "        if (live) {                                 // checkpoint: state at the start of this step\n";
+    for (int i = 0; i < N; ++i) src << "            xio[" << i << "LL * SB + b] = X(" << i << ");\n";
+    src << "        }\n";
 
     // ---- per-step terms (device_common.hpp terms_step_tran), stored to LDS or kept in registers
     const std::string i2 = "        ";
@@ -411,7 +467,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         }
     }
 
-    src << i2 << "bool active = !dead && !viol;\n"
+    src << i2 << "bool active = live;\n"
         << i2 << "int it = 0;\n"
         << i2 << "for (int iter = 0; iter < " << K.tran_max_iters << "; ++iter) {\n"
         << i2 << "    if (!__any(active)) break;\n";
@@ -454,165 +510,194 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
               << tname(tb + T_M_GD) << " * " << Vd << " - " << tname(tb + T_M_GG) << " * " << Vg << " - " << tname(tb + T_M_GS) << " * " << Vs << ";\n";
     }
 
-    // ---- assemble [G | I] symbolically (gather lists of plan.cpp, reference order).
-    // Entries are only RECORDED here; the code of an entry is emitted when the
-    // elimination first reads it (shortens live ranges: ~137 entries would
-    // otherwise all be live at once).
-    std::vector<std::vector<AV>> M(static_cast<std::size_t>(N), std::vector<AV>(static_cast<std::size_t>(N + 1)));
-    g.out << g.ind << "// assembly (lazy) + elimination\n";
-    g.pending.assign(static_cast<std::size_t>(N), std::vector<std::vector<AV>>(static_cast<std::size_t>(N + 1)));
-    const GatherPlan& gp = ap.tran;
-    for (int n = 0; n < gp.nnzG(); ++n) {
-        std::vector<AV> terms;
-        for (int c = gp.gPtr[static_cast<std::size_t>(n)]; c < gp.gPtr[static_cast<std::size_t>(n + 1)]; ++c) {
-            const int con = gp.gCon[static_cast<std::size_t>(c)];
-            AV t = termAV[static_cast<std::size_t>(con >> 1)];
-            terms.push_back((con & 1) ? g.negate(t) : t);
+    // ---- one solve body per recorded pivot schedule: assembly (lazy) + elimination with that
+    // schedule's pivots + back substitution.  Returns the abstract solution; its pivot checks
+    // accumulate into the bool named pvName.
+    const int ldsBase = ldsNext;
+    int ldsMax = ldsNext;
+    auto emitSolve = [&](const PivotSchedule& sc, const std::string& pvName) -> std::vector<AV> {
+        ldsNext = ldsBase;                 // parked slots are reused by every alternative
+        // ---- assemble [G | I] symbolically (gather lists of plan.cpp, reference order).
+        // Entries are only RECORDED here; the code of an entry is emitted when the
+        // elimination first reads it (shortens live ranges: ~137 entries would
+        // otherwise all be live at once).
+        std::vector<std::vector<AV>> M(static_cast<std::size_t>(N), std::vector<AV>(static_cast<std::size_t>(N + 1)));
+        g.out << g.ind << "// assembly (lazy) + elimination\n";
+        g.pending.assign(static_cast<std::size_t>(N), std::vector<std::vector<AV>>(static_cast<std::size_t>(N + 1)));
+        const GatherPlan& gp = ap.tran;
+        for (int n = 0; n < gp.nnzG(); ++n) {
+            std::vector<AV> terms;
+            for (int c = gp.gPtr[static_cast<std::size_t>(n)]; c < gp.gPtr[static_cast<std::size_t>(n + 1)]; ++c) {
+                const int con = gp.gCon[static_cast<std::size_t>(c)];
+                AV t = termAV[static_cast<std::size_t>(con >> 1)];
+                terms.push_back((con & 1) ? g.negate(t) : t);
+            }
+            const int pos = gp.gPos[static_cast<std::size_t>(n)];
+            g.pending[static_cast<std::size_t>(pos / LD)][static_cast<std::size_t>(pos % LD)] = terms;
+            // structural marker so that zero tests see the entry before it is materialised
+            M[static_cast<std::size_t>(pos / LD)][static_cast<std::size_t>(pos % LD)] = AV::dyn("?");
         }
-        const int pos = gp.gPos[static_cast<std::size_t>(n)];
-        g.pending[static_cast<std::size_t>(pos / LD)][static_cast<std::size_t>(pos % LD)] = terms;
-        // structural marker so that zero tests see the entry before it is materialised
-        M[static_cast<std::size_t>(pos / LD)][static_cast<std::size_t>(pos % LD)] = AV::dyn("?");
-    }
-    for (int n = 0; n < gp.nnzI(); ++n) {
-        std::vector<AV> terms;
-        for (int c = gp.iPtr[static_cast<std::size_t>(n)]; c < gp.iPtr[static_cast<std::size_t>(n + 1)]; ++c) {
-            const int con = gp.iCon[static_cast<std::size_t>(c)];
-            AV t = termAV[static_cast<std::size_t>(con >> 1)];
-            terms.push_back((con & 1) ? g.negate(t) : t);
+        for (int n = 0; n < gp.nnzI(); ++n) {
+            std::vector<AV> terms;
+            for (int c = gp.iPtr[static_cast<std::size_t>(n)]; c < gp.iPtr[static_cast<std::size_t>(n + 1)]; ++c) {
+                const int con = gp.iCon[static_cast<std::size_t>(c)];
+                AV t = termAV[static_cast<std::size_t>(con >> 1)];
+                terms.push_back((con & 1) ? g.negate(t) : t);
+            }
+            const int r = gp.iRow[static_cast<std::size_t>(n)];
+            g.pending[static_cast<std::size_t>(r)][static_cast<std::size_t>(N)] = terms;
+            M[static_cast<std::size_t>(r)][static_cast<std::size_t>(N)] = AV::dyn("?");
         }
-        const int r = gp.iRow[static_cast<std::size_t>(n)];
-        g.pending[static_cast<std::size_t>(r)][static_cast<std::size_t>(N)] = terms;
-        M[static_cast<std::size_t>(r)][static_cast<std::size_t>(N)] = AV::dyn("?");
-    }
-    // resolve every all-constant entry now (they cost no code and decide the zero pattern)
-    for (int r = 0; r < N; ++r)
-        for (int c = 0; c <= N; ++c) {
+        // resolve every all-constant entry now (they cost no code and decide the zero pattern)
+        for (int r = 0; r < N; ++r)
+            for (int c = 0; c <= N; ++c) {
+                auto& pend = g.pending[static_cast<std::size_t>(r)][static_cast<std::size_t>(c)];
+                if (pend.empty()) continue;
+                bool allConst = true;
+                for (const AV& t : pend) allConst = allConst && t.kind != AV::DYN;
+                if (allConst) { M[static_cast<std::size_t>(r)][static_cast<std::size_t>(c)] = g.orderedSum(pend); pend.clear(); }
+            }
+        // materialise on first use
+        auto at = [&](int r, int c) -> AV& {
             auto& pend = g.pending[static_cast<std::size_t>(r)][static_cast<std::size_t>(c)];
-            if (pend.empty()) continue;
-            bool allConst = true;
-            for (const AV& t : pend) allConst = allConst && t.kind != AV::DYN;
-            if (allConst) { M[static_cast<std::size_t>(r)][static_cast<std::size_t>(c)] = g.orderedSum(pend); pend.clear(); }
+            AV& slot = M[static_cast<std::size_t>(r)][static_cast<std::size_t>(c)];
+            if (!pend.empty()) { slot = g.orderedSum(pend); pend.clear(); }
+            return slot;
+        };
+
+        // ---- elimination with the scheduled pivots (solver.hpp:46-77), RHS carried along
+        std::vector<AV> rinv(static_cast<std::size_t>(N));      // 1 / U(k,k)
+        int parked = 0;
+        const int splitEvery = std::getenv("CSIM_CG_SPLIT") ? std::max(1, std::atoi(std::getenv("CSIM_CG_SPLIT"))) : 0;
+        for (int k = 0; k < N; ++k) {
+            const int p = sc.pivotPos[static_cast<std::size_t>(k)];
+            const AV ap_ = at(p, k);
+            g.out << g.ind << "// column " << k << ": pivot row position " << p << "\n";
+            // Tuning knob (off by default): a basic-block boundary every CSIM_CG_SPLIT columns through a
+            // scalar branch on an opaque, never-true flag.  hipcc schedules each basic block for ILP and
+            // inflates the live set of this 3000-instruction body; the short-circuit "pv = pv || ..."
+            // chains below already split it (turning them into branch-free "|=" was measured 37 %
+            // slower: 6.5e8 -> 4.1e8), extra boundaries were measured neutral (6.3e8).
+            if (splitEvery > 0 && (k % splitEvery) == 0)
+                g.out << g.ind << "if (splitFlag) asm volatile(\"s_nop 0\");\n";
+            // the reference picks the FIRST row attaining the column maximum (solver.hpp:48-56)
+            // and fails below 1e-15 (:58-61)
+            if (ap_.isZero()) {
+                g.out << g.ind << pvName << " = true;   // scheduled pivot is a structural zero\n";
+            } else {
+                const std::string absP = ap_.kind == AV::CONST ? lit(std::fabs(ap_.c)) : "fabs(" + ap_.v + ")";
+                if (ap_.kind == AV::DYN) {
+                    g.out << g.ind << pvName << " = " << pvName << " || !(" << absP << " >= " << lit(K.lu_eps) << ");\n";
+                    ++g.st.nCmp;
+                } else if (std::fabs(ap_.c) < K.lu_eps) {
+                    g.out << g.ind << pvName << " = true;\n";
+                }
+                for (int i = k; i < N; ++i) {
+                    if (i == p) continue;
+                    const AV& ai = at(i, k);
+                    if (ai.isZero()) continue;
+                    const bool before = i < p;
+                    if (ai.kind == AV::CONST && ap_.kind == AV::CONST) {
+                        const bool ok = before ? (std::fabs(ap_.c) > std::fabs(ai.c)) : (std::fabs(ap_.c) >= std::fabs(ai.c));
+                        if (!ok) g.out << g.ind << pvName << " = true;   // schedule contradicts constant entries\n";
+                        continue;
+                    }
+                    const std::string absI = ai.kind == AV::CONST ? lit(std::fabs(ai.c)) : "fabs(" + ai.v + ")";
+                    g.out << g.ind << pvName << " = " << pvName << " || !(" << absP << (before ? " > " : " >= ") << absI << ");\n";
+                    ++g.st.nCmp;
+                }
+            }
+            if (p != k) {
+                std::swap(M[static_cast<std::size_t>(p)], M[static_cast<std::size_t>(k)]);
+                std::swap(g.pending[static_cast<std::size_t>(p)], g.pending[static_cast<std::size_t>(k)]);
+            }
+            const AV piv = at(k, k);
+            AV r;
+            if (piv.kind == AV::CONST) r = AV::konst(1.0 / piv.c);
+            else if (piv.kind == AV::DYN) { r = g.emit("rcp_nr(" + g.ref(piv) + ")"); ++g.st.nRecip; }
+            rinv[static_cast<std::size_t>(k)] = r;
+            for (int i = k + 1; i < N; ++i) {
+                const AV aik = at(i, k);
+                if (aik.isZero()) continue;
+                ++g.st.nLower;
+                const AV f = g.mul(aik, r);                                  // multiplier (solver.hpp:71)
+                for (int j = k + 1; j <= N; ++j) {
+                    if (M[static_cast<std::size_t>(k)][static_cast<std::size_t>(j)].isZero()) continue;
+                    const AV u = at(k, j);
+                    if (u.isZero()) continue;
+                    const AV a = at(i, j);
+                    M[static_cast<std::size_t>(i)][static_cast<std::size_t>(j)] = g.fnma(a, f, u);   // :74
+                }
+                M[static_cast<std::size_t>(i)][static_cast<std::size_t>(k)] = AV::zero();
+            }
+            // row k is final: it is next read in the back substitution.  The rich variant parks
+            // its run-time entries (and the pivot reciprocal) in LDS instead of leaving it to the
+            // register allocator to spill them to scratch.
+            if (opt.parkBudget != 0) {
+                for (int j = k + 1; j <= N; ++j) {
+                    if (M[static_cast<std::size_t>(k)][static_cast<std::size_t>(j)].isZero()) continue;
+                    const AV v = at(k, j);
+                    if (v.kind != AV::DYN) continue;
+                    if (opt.parkBudget > 0 && parked >= opt.parkBudget) break;
+                    ++parked;
+                    const std::string q = qslot();
+                    g.out << g.ind << q << " = " << g.ref(v) << ";\n";
+                    M[static_cast<std::size_t>(k)][static_cast<std::size_t>(j)] = AV::dyn(q);
+                }
+                if (r.kind == AV::DYN && (opt.parkBudget < 0 || parked < opt.parkBudget)) {
+                    ++parked;
+                    const std::string q = qslot();
+                    g.out << g.ind << q << " = " << g.ref(r) << ";\n";
+                    rinv[static_cast<std::size_t>(k)] = AV::dyn(q);
+                }
+            }
         }
-    // materialise on first use
-    auto at = [&](int r, int c) -> AV& {
-        auto& pend = g.pending[static_cast<std::size_t>(r)][static_cast<std::size_t>(c)];
-        AV& slot = M[static_cast<std::size_t>(r)][static_cast<std::size_t>(c)];
-        if (!pend.empty()) { slot = g.orderedSum(pend); pend.clear(); }
-        return slot;
+
+        // ---- back substitution (solver.hpp:116-128): row i descending, j ascending
+        g.out << g.ind << "// back substitution\n";
+        std::vector<AV> xr(static_cast<std::size_t>(N));
+        for (int i = N - 1; i >= 0; --i) {
+            AV sum = at(i, N);
+            for (int j = i + 1; j < N; ++j) {
+                if (M[static_cast<std::size_t>(i)][static_cast<std::size_t>(j)].isZero()) continue;
+                const AV u = at(i, j);
+                if (u.isZero()) continue;
+                if (u.kind == AV::DYN) ++g.st.nDynU;
+                sum = g.fnma(sum, u, xr[static_cast<std::size_t>(j)]);
+            }
+            xr[static_cast<std::size_t>(i)] = g.mul(sum, rinv[static_cast<std::size_t>(i)]);
+        }
+
+
+        if (ldsNext > ldsMax) ldsMax = ldsNext;
+        return xr;
     };
 
-    // ---- elimination with the scheduled pivots (solver.hpp:46-77), RHS carried along
-    g.out << g.ind << "bool pv = false;     // a pivot check failed in this iteration\n";
-    std::vector<AV> rinv(static_cast<std::size_t>(N));      // 1 / U(k,k)
-    int parked = 0;
-    const int splitEvery = std::getenv("CSIM_CG_SPLIT") ? std::max(1, std::atoi(std::getenv("CSIM_CG_SPLIT"))) : 0;
-    for (int k = 0; k < N; ++k) {
-        const int p = sch.pivotPos[static_cast<std::size_t>(k)];
-        const AV ap_ = at(p, k);
-        g.out << g.ind << "// column " << k << ": pivot row position " << p << "\n";
-        // Tuning knob (off by default): a basic-block boundary every CSIM_CG_SPLIT columns through a
-        // scalar branch on an opaque, never-true flag.  hipcc schedules each basic block for ILP and
-        // inflates the live set of this 3000-instruction body; the short-circuit "pv = pv || ..."
-        // chains below already split it (turning them into branch-free "|=" was measured 37 %
-        // slower: 6.5e8 -> 4.1e8), extra boundaries were measured neutral (6.3e8).
-        if (splitEvery > 0 && (k % splitEvery) == 0)
-            g.out << g.ind << "if (splitFlag) asm volatile(\"s_nop 0\");\n";
-        // the reference picks the FIRST row attaining the column maximum (solver.hpp:48-56)
-        // and fails below 1e-15 (:58-61)
-        if (ap_.isZero()) {
-            g.out << g.ind << "pv = true;   // scheduled pivot is a structural zero\n";
-        } else {
-            const std::string absP = ap_.kind == AV::CONST ? lit(std::fabs(ap_.c)) : "fabs(" + ap_.v + ")";
-            if (ap_.kind == AV::DYN) {
-                g.out << g.ind << "pv = pv || !(" << absP << " >= " << lit(K.lu_eps) << ");\n";
-                ++g.st.nCmp;
-            } else if (std::fabs(ap_.c) < K.lu_eps) {
-                g.out << g.ind << "pv = true;\n";
-            }
-            for (int i = k; i < N; ++i) {
-                if (i == p) continue;
-                const AV& ai = at(i, k);
-                if (ai.isZero()) continue;
-                const bool before = i < p;
-                if (ai.kind == AV::CONST && ap_.kind == AV::CONST) {
-                    const bool ok = before ? (std::fabs(ap_.c) > std::fabs(ai.c)) : (std::fabs(ap_.c) >= std::fabs(ai.c));
-                    if (!ok) g.out << g.ind << "pv = true;   // schedule contradicts constant entries\n";
-                    continue;
-                }
-                const std::string absI = ai.kind == AV::CONST ? lit(std::fabs(ai.c)) : "fabs(" + ai.v + ")";
-                g.out << g.ind << "pv = pv || !(" << absP << (before ? " > " : " >= ") << absI << ");\n";
-                ++g.st.nCmp;
-            }
+    // ---- the alternatives are tried in order; lanes whose checks failed take the next one
+    g.out << g.ind << "bool pv = false;     // every schedule tried so far failed its pivot checks\n";
+    for (int i = 0; i < N; ++i) g.out << g.ind << "double xr" << i << ";\n";
+    for (std::size_t alt = 0; alt < set.alts.size(); ++alt) {
+        const std::string pvName = "pvA" + std::to_string(alt);
+        if (alt == 0) g.out << g.ind << "{\n";
+        else g.out << g.ind << "if (__any(active && pv)) {   // alternative schedule " << alt << "\n";
+        g.out << g.ind << "bool " << pvName << " = false;\n";
+        const std::vector<AV> sol = emitSolve(set.alts[alt], pvName);
+        for (int i = 0; i < N; ++i) {
+            if (alt == 0) g.out << g.ind << "xr" << i << " = " << g.ref(sol[static_cast<std::size_t>(i)]) << ";\n";
+            else g.out << g.ind << "xr" << i << " = pv ? " << g.ref(sol[static_cast<std::size_t>(i)]) << " : xr" << i << ";\n";
         }
-        if (p != k) {
-            std::swap(M[static_cast<std::size_t>(p)], M[static_cast<std::size_t>(k)]);
-            std::swap(g.pending[static_cast<std::size_t>(p)], g.pending[static_cast<std::size_t>(k)]);
-        }
-        const AV piv = at(k, k);
-        AV r;
-        if (piv.kind == AV::CONST) r = AV::konst(1.0 / piv.c);
-        else if (piv.kind == AV::DYN) { r = g.emit("rcp_nr(" + g.ref(piv) + ")"); ++g.st.nRecip; }
-        rinv[static_cast<std::size_t>(k)] = r;
-        for (int i = k + 1; i < N; ++i) {
-            const AV aik = at(i, k);
-            if (aik.isZero()) continue;
-            ++g.st.nLower;
-            const AV f = g.mul(aik, r);                                  // multiplier (solver.hpp:71)
-            for (int j = k + 1; j <= N; ++j) {
-                if (M[static_cast<std::size_t>(k)][static_cast<std::size_t>(j)].isZero()) continue;
-                const AV u = at(k, j);
-                if (u.isZero()) continue;
-                const AV a = at(i, j);
-                M[static_cast<std::size_t>(i)][static_cast<std::size_t>(j)] = g.fnma(a, f, u);   // :74
-            }
-            M[static_cast<std::size_t>(i)][static_cast<std::size_t>(k)] = AV::zero();
-        }
-        // row k is final: it is next read in the back substitution.  The rich variant parks
-        // its run-time entries (and the pivot reciprocal) in LDS instead of leaving it to the
-        // register allocator to spill them to scratch.
-        if (opt.parkBudget != 0) {
-            for (int j = k + 1; j <= N; ++j) {
-                if (M[static_cast<std::size_t>(k)][static_cast<std::size_t>(j)].isZero()) continue;
-                const AV v = at(k, j);
-                if (v.kind != AV::DYN) continue;
-                if (opt.parkBudget > 0 && parked >= opt.parkBudget) break;
-                ++parked;
-                const std::string q = qslot();
-                g.out << g.ind << q << " = " << g.ref(v) << ";\n";
-                M[static_cast<std::size_t>(k)][static_cast<std::size_t>(j)] = AV::dyn(q);
-            }
-            if (r.kind == AV::DYN && (opt.parkBudget < 0 || parked < opt.parkBudget)) {
-                ++parked;
-                const std::string q = qslot();
-                g.out << g.ind << q << " = " << g.ref(r) << ";\n";
-                rinv[static_cast<std::size_t>(k)] = AV::dyn(q);
-            }
-        }
+        if (alt == 0) g.out << g.ind << "pv = " << pvName << ";\n";
+        else g.out << g.ind << "pv = pv && " << pvName << ";\n";
+        g.out << g.ind << "}\n";
     }
-
-    // ---- back substitution (solver.hpp:116-128): row i descending, j ascending
-    g.out << g.ind << "// back substitution\n";
-    std::vector<AV> xr(static_cast<std::size_t>(N));
-    for (int i = N - 1; i >= 0; --i) {
-        AV sum = at(i, N);
-        for (int j = i + 1; j < N; ++j) {
-            if (M[static_cast<std::size_t>(i)][static_cast<std::size_t>(j)].isZero()) continue;
-            const AV u = at(i, j);
-            if (u.isZero()) continue;
-            if (u.kind == AV::DYN) ++g.st.nDynU;
-            sum = g.fnma(sum, u, xr[static_cast<std::size_t>(j)]);
-        }
-        xr[static_cast<std::size_t>(i)] = g.mul(sum, rinv[static_cast<std::size_t>(i)]);
-    }
+    ldsNext = ldsMax;
 
     // ---- damped update, norm in index order, convergence (tanalisis.cpp:360-376)
     std::ostringstream& o = g.out;
     o << g.ind << "double ss = 0.0;\n";
     for (int i = 0; i < N; ++i) {
-        const AV& v = xr[static_cast<std::size_t>(i)];
         o << g.ind << "const double xo" << i << " = X(" << i << ");\n"
-          << g.ind << "const double xn" << i << " = xo" << i << " + " << lit(K.tran_alpha) << " * (" << g.ref(v) << " - xo" << i << ");\n"
+          << g.ind << "const double xn" << i << " = xo" << i << " + " << lit(K.tran_alpha) << " * (xr" << i << " - xo" << i << ");\n"
           << g.ind << "{ const double d = xn" << i << " - xo" << i << "; ss += d * d; }\n";
     }
     // a non-finite solve (tanalisis.cpp:360-362) makes ss non-finite; so does an overflow of
@@ -630,22 +715,24 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
 
     src << g.out.str();
     src << i2 << "}\n"      // NR loop
-        << i2 << "itTotal += it;\n"
-        << i2 << "if (inb && !viol) {\n"
+        << i2 << "if (live && !viol) {\n"
+        << i2 << "    itTotal += it;\n"
         << i2 << "    if (stepIters) stepIters[(s - 1) * SB + b] = it;\n"
         << i2 << "    if (wave && !dead && (gstep % outStride) == 0) {\n"
         << i2 << "        const long long row = gstep / outStride;\n"
         << i2 << "        for (int q = 0; q < nProbe; ++q) wave[(row * nProbe + q) * SB + b] = X(probeEq[q]);\n"
         << i2 << "    }\n"
+        << i2 << "    sdone = dead ? nSteps : s;\n"
         << i2 << "}\n"
         << "    }\n\n"
         << "    if (inb) {\n"
-        << "        if (viol) { fallback[b] = 1; }\n"
+        << "        if (viol) fallback[b] = 1;               // xio holds the checkpoint of the step that failed\n"
         << "        else {\n";
     for (int i = 0; i < N; ++i) src << "            xio[" << i << "LL * SB + b] = X(" << i << ");\n";
-    src << "            iters[b] += itTotal;\n"
-        << "            status[b] |= st;\n"
-        << "        }\n"
+    src << "        }\n"
+        << "        iters[b] += itTotal;\n"
+        << "        status[b] |= st;\n"
+        << "        done[b] = (int)sdone;\n"
         << "    }\n"
         << "}\n\n";
 
@@ -655,15 +742,16 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
 
 } // namespace
 
-std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch,
+std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, const ScheduleSet& set,
                                      const std::string& label, CodegenStats* statsOut)
 {
     const int N = ir.n_unknowns;
-    const uint64_t hash = scheduleHash(ir, sch);
+    const uint64_t hash = scheduleHash(ir, set);
+    if (set.alts.empty()) return std::string();
     std::ostringstream src;
     src << "// GENERATED by circuitsimulator_amd/csrc/engine/codegen.cpp -- do not edit.\n"
         << "// circuit: " << label << "   N=" << N << "  elements=" << ir.n_elems << "  P=" << ir.n_params << "\n"
-        << "// pivot schedule (column:row position): " << (sch.str().empty() ? "identity" : sch.str()) << "\n"
+        << "// pivot schedules (column:row position), tried in this order: " << set.str() << "\n"
         << "// One lane = one circuit instance; see codegen.hpp for what is and is not\n"
         << "// identical to the reference arithmetic.  Two variants of the same arithmetic:\n"
         << "//   csim_tran_sched_kernel       x and as many finished U-row values as fit 40 KB of LDS per\n"
@@ -683,7 +771,7 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     // a variant is emitted only if its LDS image fits one CU (163 840 B)
     auto emitVariant = [&](const VariantOptions& opt, CodegenStats* st) {
         std::ostringstream k;
-        const int ldsDoubles = emitKernel(k, ir, ap, sch, opt, st);
+        const int ldsDoubles = emitKernel(k, ir, ap, set, opt, st);
         if (ldsDoubles * 512 > 160 * 1024) return -1;
         std::string text = k.str();
         const std::string token = "@LDS_DOUBLES@";
@@ -720,30 +808,36 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     src << "extern \"C\" unsigned long long csim_sched_hash(void) { return " << hbuf << "; }\n"
         << "extern \"C\" unsigned long long csim_sched_topology(void) { return " << tbuf << "; }\n"
         << "extern \"C\" const char* csim_sched_info(void) { return \"" << label << " N=" << N << " schedule="
-        << (sch.str().empty() ? "identity" : sch.str()) << " lds_doubles_per_lane=" << ldsLean << "/" << ldsRich << "\"; }\n"
+        << set.str() << " lds_doubles_per_lane=" << ldsLean << "/" << ldsRich << "\"; }\n"
+        << "// the recorded alternatives, [n_alts][N] pivot row positions (the engine hands them to the\n"
+        << "// general kernel so that it can tell when an instance is back on a known sequence)\n"
+        << "extern \"C\" const int* csim_sched_alts(int* nAlts, int* n)\n{\n    static const int table[] = {";
+    for (std::size_t a = 0; a < set.alts.size(); ++a)
+        for (int k = 0; k < N; ++k) src << (a + k ? ", " : "") << set.alts[a].pivotPos[static_cast<std::size_t>(k)];
+    src << "};\n    *nAlts = " << set.alts.size() << ";\n    *n = " << N << ";\n    return table;\n}\n"
         << "// variant: 0/1 = lean (measured fastest at every batch size: park-budget sweep in DESIGN.md),\n"
         << "//          2 = rich (tuning aid), 10+k = sweep kernels when generated with CSIM_CG_SWEEP\n"
         << "extern \"C\" int csim_sched_launch(const double* params, int B, double dt, long long stepFirst, long long nSteps,\n"
         << "                                 const int* probeEq, int nProbe, int outStride, double* wave, double* xio,\n"
         << "                                 long long* iters, unsigned* status, int* stepIters, unsigned char* fallback,\n"
-        << "                                 void* stream, int variant)\n{\n"
+        << "                                 int* done, void* stream, int variant)\n{\n"
         << "    if (B <= 0) return 0;\n"
         << "    const unsigned waves = (unsigned)((B + 63) / 64);\n"
         << "    const bool rich = " << (haveRich ? "(variant == 2)" : "false") << ";\n"
         ;
     for (std::size_t k = 0; k < sweep.size(); ++k)
         src << "    if (variant == " << (10 + k) << ") { hipLaunchKernelGGL(csim_tran_sched_kernel_sweep" << k
-            << ", dim3(waves), dim3(64), 0, (hipStream_t)stream, params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status, stepIters, fallback); return (int)hipGetLastError(); }\n";
+            << ", dim3(waves), dim3(64), 0, (hipStream_t)stream, params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status, stepIters, fallback, done); return (int)hipGetLastError(); }\n";
     if (haveRich)
         src << "    if (rich) {\n"
             << "        hipLaunchKernelGGL(csim_tran_sched_kernel_rich, dim3(waves), dim3(64), 0, (hipStream_t)stream,\n"
             << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
-            << "                           stepIters, fallback);\n"
+            << "                           stepIters, fallback, done);\n"
             << "        return (int)hipGetLastError();\n    }\n";
     src << "    (void)rich;\n"
         << "    hipLaunchKernelGGL(csim_tran_sched_kernel, dim3(waves), dim3(64), 0, (hipStream_t)stream,\n"
         << "                       params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
-        << "                       stepIters, fallback);\n"
+        << "                       stepIters, fallback, done);\n"
         << "    return (int)hipGetLastError();\n}\n";
     return src.str();
 }

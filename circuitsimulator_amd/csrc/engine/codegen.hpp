@@ -46,15 +46,26 @@ struct PivotSchedule {
     std::string str() const;
 };
 
+// Several schedules of one circuit (a switching circuit alternates between a few pivot
+// sequences).  The generated kernel carries one solve body per alternative and tries them in
+// order, per Newton iteration, for the lanes whose pivot checks failed so far.
+struct ScheduleSet {
+    std::vector<PivotSchedule> alts;       // most frequent first
+    // one schedule per line (or ';'-separated); '#' starts a comment; "-" = no swaps
+    static bool parse(const std::string& text, int N, ScheduleSet& out);
+    std::string str() const;
+};
+
 // identifies (topology, constants, schedule); names the generated library
 uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch);
+uint64_t scheduleHash(const csim_ir& ir, const ScheduleSet& set);
 
 struct CodegenStats {
     int nMul = 0, nFma = 0, nAddSub = 0, nRecip = 0, nCmp = 0, nDynU = 0, nLower = 0;
 };
 
 // complete .hip translation unit: kernel + extern "C" launcher + metadata
-std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch,
+std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, const ScheduleSet& set,
                                      const std::string& label, CodegenStats* stats);
 
 } // namespace csim

@@ -35,7 +35,7 @@ struct GenPlan {
 
 // LDS carve-up (in doubles) for one instance
 struct LdsLayout {
-    int G, T, P, xs, xp, sc, total;
+    int G, T, P, xs, xp, sc, piv, total;
 };
 __host__ __device__ inline LdsLayout ldsLayout(int N, int LD, int nTerms, int P)
 {
@@ -46,7 +46,8 @@ __host__ __device__ inline LdsLayout ldsLayout(int N, int LD, int nTerms, int P)
     l.xs = l.P + P;
     l.xp = l.xs + N;
     l.sc = l.G;                 // norm scratch aliases the matrix (dead after the solve)
-    l.total = l.xp + N;
+    l.piv = l.xp + N;           // N int32: pivot sequence of the current factorisation
+    l.total = l.piv + (N + 1) / 2;
     return l;
 }
 
@@ -251,6 +252,56 @@ __device__ __forceinline__ void assemble(const GenPlan& pl, const double* T, dou
     wave_sync();
 }
 
+// is the pivot sequence in curPiv (LDS, N ints) one of the nAlts known ones ([nAlts][N], global)?
+__device__ __forceinline__ bool sequence_is_known(const int32_t* curPiv, const int32_t* alts, int nAlts, int N, int lane)
+{
+    wave_sync();
+    bool known = false;
+    for (int a = 0; a < nAlts && !known; ++a) {
+        bool same = true;
+        for (int k = lane; k < N; k += 64) same = same && (curPiv[k] == alts[a * N + k]);
+        known = __ballot(!same) == 0ull;
+    }
+    return known;
+}
+
+// ---- planner log (global memory, one per recorded instance):
+//   [0] number of distinct sequences stored (<= PIVLOG_MAX)   [1] factorisations seen
+//   [2] factorisations that failed or did not fit the table
+//   then PIVLOG_MAX records of (N positions + 1 count), then N ints of the sequence in progress
+constexpr int PIVLOG_MAX = 8;
+__host__ __device__ inline int pivlog_ints(int N) { return 3 + PIVLOG_MAX * (N + 1) + N; }
+__device__ __forceinline__ int32_t* pivlog_cur(int32_t* log, int N) { return log + 3 + PIVLOG_MAX * (N + 1); }
+__device__ __forceinline__ void pivlog_commit(int32_t* log, int N, bool failed, int lane)
+{
+    __threadfence_block();
+    wave_sync();
+    if (lane == 0) {
+        log[1] += 1;
+        if (failed) log[2] += 1;
+        else {
+            const int32_t* cur = pivlog_cur(log, N);
+            int hit = -1;
+            for (int s = 0; s < log[0] && hit < 0; ++s) {
+                const int32_t* rec = log + 3 + s * (N + 1);
+                bool same = true;
+                for (int k = 0; k < N && same; ++k) same = rec[k] == cur[k];
+                if (same) hit = s;
+            }
+            if (hit < 0 && log[0] < PIVLOG_MAX) {
+                hit = log[0];
+                int32_t* rec = log + 3 + hit * (N + 1);
+                for (int k = 0; k < N; ++k) rec[k] = cur[k];
+                rec[N] = 0;
+                log[0] += 1;
+            }
+            if (hit >= 0) log[3 + hit * (N + 1) + N] += 1; else log[2] += 1;
+        }
+    }
+    __threadfence_block();
+    wave_sync();
+}
+
 // ---- wavefront-cooperative LU with partial pivoting + substitution on the
 // augmented LDS matrix (N <= 63: row i and column j are owned by lane i / j,
 // the RHS is column N).
@@ -266,14 +317,12 @@ __device__ __forceinline__ void assemble(const GenPlan& pl, const double* T, dou
 //
 // Returns the solution component of lane i (< N) and ORs CSIM_ST_LU_* flags.
 //
-// pivLog (optional, planner): int32 [N + 2] in global memory: the pivot row position of
-// every column for the FIRST factorisation seen, then the number of factorisations and
-// the number whose sequence differed from the first.
+// pivLog (optional, planner): see PIVLOG_* below -- the distinct pivot sequences seen, with
+// how many factorisations used each.
 __device__ __forceinline__ double lu_solve_wave(double* Gm, int N, int LD, double eps, int lane, unsigned& flags,
-                                                int32_t* pivLog = nullptr)
+                                                int32_t* pivLog = nullptr, int32_t* curPiv = nullptr)
 {
-    const bool logFirst = pivLog && pivLog[N] == 0;
-    bool logDiffer = false;
+    int32_t* const logCur = pivLog ? pivlog_cur(pivLog, N) : nullptr;
     double diag = 1.0;          // lane k keeps U(k,k)
     bool failed = false;
 
@@ -297,10 +346,8 @@ __device__ __forceinline__ double lu_solve_wave(double* Gm, int N, int LD, doubl
             }
         }
         if (maxAbs < eps) { failed = true; break; }
-        if (pivLog) {
-            if (logFirst) { if (lane == 0) pivLog[k] = piv; }
-            else if (pivLog[k] != piv) logDiffer = true;
-        }
+        if (logCur && lane == 0) logCur[k] = piv;
+        if (curPiv && lane == 0) curPiv[k] = piv;      // LDS: this factorisation's sequence (hybrid stepping)
 
         if (piv != k) {         // swap rows k and piv (columns >= k and the RHS)
             if (lane >= k && lane <= N) {
@@ -331,10 +378,7 @@ __device__ __forceinline__ double lu_solve_wave(double* Gm, int N, int LD, doubl
         wave_sync();
     }
 
-    if (pivLog && lane == 0) {
-        pivLog[N] += 1;
-        if (logDiffer || (failed && !logFirst)) pivLog[N + 1] += 1;
-    }
+    if (pivLog) pivlog_commit(pivLog, N, failed, lane);
     if (failed) {
         flags |= CSIM_ST_LU_TINY_PIVOT;
         return 0.0;

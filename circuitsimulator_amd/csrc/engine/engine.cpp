@@ -128,6 +128,22 @@ std::string ownDirectory()
     return slash == std::string::npos ? std::string(".") : path.substr(0, slash);
 }
 
+// the alternatives a generated library carries -> device table for the general kernel's hand-back test
+void adoptScheduleTable(csim_engine* eng, void* lib)
+{
+    typedef const int* (*AltsFn)(int*, int*);
+    AltsFn fn = reinterpret_cast<AltsFn>(dlsym(lib, "csim_sched_alts"));
+    eng->nKnownAlts = 0;
+    if (eng->dKnownAlts) { (void)hipFree(eng->dKnownAlts); eng->dKnownAlts = nullptr; }
+    if (!fn) return;
+    int nAlts = 0, n = 0;
+    const int* table = fn(&nAlts, &n);
+    if (!table || nAlts <= 0 || n != eng->plan.N) return;
+    if (hipMalloc(reinterpret_cast<void**>(&eng->dKnownAlts), sizeof(int32_t) * (size_t)nAlts * n) != hipSuccess) return;
+    if (hipMemcpy(eng->dKnownAlts, table, sizeof(int32_t) * (size_t)nAlts * n, hipMemcpyHostToDevice) != hipSuccess) return;
+    eng->nKnownAlts = nAlts;
+}
+
 // look for a generated kernel of this topology next to libcsim.so
 void loadScheduledKernel(csim_engine* eng)
 {
@@ -147,6 +163,7 @@ void loadScheduledKernel(csim_engine* eng)
     eng->schedLib = lib;
     eng->schedLaunch = launch;
     eng->schedInfo = infoFn ? infoFn() : "";
+    adoptScheduleTable(eng, lib);
     if (const char* v = std::getenv("CSIM_SCHED_VARIANT")) eng->schedVariant = std::atoi(v);
 }
 
@@ -207,6 +224,8 @@ void csim_engine_destroy(csim_engine* eng)
     (void)hipSetDevice(eng->device);
     for (void* p : eng->owned) (void)hipFree(p);
     if (eng->dFallback) (void)hipFree(eng->dFallback);
+    if (eng->dDone) (void)hipFree(eng->dDone);
+    if (eng->dKnownAlts) (void)hipFree(eng->dKnownAlts);
     if (eng->dBigScratch) (void)hipFree(eng->dBigScratch);
     if (eng->schedLib) dlclose(eng->schedLib);
     delete eng;
@@ -280,34 +299,58 @@ int csim_tran_batch_dev(csim_engine* eng, const double* d_params, int32_t B, dou
     }
     hipStream_t hs = static_cast<hipStream_t>(stream);
     const int np = d_wave ? n_probe : 0, os = d_wave ? out_stride : 1;
-    const uint8_t* only = nullptr;
-    if (eng->schedLaunch && eng->kernelChoice != 1) {
-        // fast path: lane-per-instance generated kernel; instances whose pivot
-        // checks fail are left untouched and marked in the mask ...
-        if (eng->fallbackCap < B) {
-            if (eng->dFallback) HIPCHK(hipFree(eng->dFallback));
-            eng->dFallback = nullptr;
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dFallback), (size_t)B));
-            eng->fallbackCap = B;
+    auto general = [&](int32_t* dDone, int maxSteps) -> int {
+        if (eng->big) {
+            const int rc = ensureBigScratch(eng, B, hs);
+            if (rc) return rc;
+            HIPCHK(csim::launchTranBig(eng->gpTran, d_params, B, tstep, step_first, n_steps, dProbe, np, os, d_wave, d_x,
+                                       reinterpret_cast<long long*>(d_iters), d_status, d_step_iters, nullptr,
+                                       eng->dBigScratch, nullptr, hs, nullptr, -1, dDone, maxSteps));
+        } else {
+            HIPCHK(csim::launchTranGeneral(eng->gpTran, d_params, B, tstep, step_first, n_steps, dProbe, np, os, d_wave, d_x,
+                                           reinterpret_cast<long long*>(d_iters), d_status, d_step_iters, nullptr, hs,
+                                           nullptr, -1, dDone, maxSteps, dDone ? eng->dKnownAlts : nullptr,
+                                           dDone ? eng->nKnownAlts : 0));
         }
-        HIPCHK(hipMemsetAsync(eng->dFallback, 0, (size_t)B, hs));
+        return CSIM_OK;
+    };
+    if (!(eng->schedLaunch && eng->kernelChoice != 1)) return general(nullptr, 0);
+
+    // Fast path with hybrid stepping.  The generated lane-per-instance kernel advances every
+    // instance until the launch is complete or one of its pivot checks fails (no recorded
+    // schedule fits that factorisation); it checkpoints the state at the start of the failing
+    // step and records per-instance progress in dDone.  The general kernel then advances the
+    // unfinished instances by a couple of steps with run-time pivoting and hands them back.
+    // Blocks/lanes with nothing left exit at once, so the extra launches cost microseconds.
+    if (eng->fallbackCap < B) {
+        if (eng->dFallback) HIPCHK(hipFree(eng->dFallback));
+        if (eng->dDone) HIPCHK(hipFree(eng->dDone));
+        eng->dFallback = nullptr;
+        eng->dDone = nullptr;
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dFallback), (size_t)B));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dDone), sizeof(int32_t) * (size_t)B));
+        eng->fallbackCap = B;
+    }
+    HIPCHK(hipMemsetAsync(eng->dFallback, 0, (size_t)B, hs));
+    HIPCHK(hipMemsetAsync(eng->dDone, 0, sizeof(int32_t) * (size_t)B, hs));
+    auto scheduled = [&]() -> int {
         const int lrc = eng->schedLaunch(d_params, B, tstep, step_first, n_steps, dProbe, np, os, d_wave, d_x,
                                          reinterpret_cast<long long*>(d_iters), d_status, d_step_iters,
-                                         eng->dFallback, stream, eng->schedVariant);
+                                         eng->dFallback, eng->dDone, stream, eng->schedVariant);
         if (lrc != 0) { setError(std::string("scheduled kernel launch: ") + hipGetErrorString((hipError_t)lrc)); return CSIM_ERR_HIP; }
-        only = eng->dFallback;      // ... and re-run below by the general kernel (blocks of unmarked instances exit at once)
-    }
-    if (eng->big) {
-        const int rc = ensureBigScratch(eng, B, hs);
-        if (rc) return rc;
-        HIPCHK(csim::launchTranBig(eng->gpTran, d_params, B, tstep, step_first, n_steps, dProbe, np, os, d_wave, d_x,
-                                   reinterpret_cast<long long*>(d_iters), d_status, d_step_iters, only,
-                                   eng->dBigScratch, nullptr, hs));
         return CSIM_OK;
+    };
+    int rc = scheduled();
+    if (rc) return rc;
+    // one round per violation episode; the general kernel keeps an instance until a whole step ran on
+    // recorded sequences again (small kernels) or for at most handBackAfter steps
+    static const int rounds = std::getenv("CSIM_HYBRID_ROUNDS") ? std::atoi(std::getenv("CSIM_HYBRID_ROUNDS")) : 8;
+    static const int handBackAfter = std::getenv("CSIM_HYBRID_STEPS") ? std::atoi(std::getenv("CSIM_HYBRID_STEPS")) : 64;
+    for (int r = 0; r < rounds; ++r) {
+        if ((rc = general(eng->dDone, handBackAfter))) return rc;
+        if ((rc = scheduled())) return rc;
     }
-    HIPCHK(csim::launchTranGeneral(eng->gpTran, d_params, B, tstep, step_first, n_steps, dProbe, np, os, d_wave, d_x,
-                                   reinterpret_cast<long long*>(d_iters), d_status, d_step_iters, only, hs));
-    return CSIM_OK;
+    return general(eng->dDone, 2147483647);      // whatever is still unfinished runs to the end of the launch
 }
 
 int64_t csim_tran_num_steps(double tstep, double tstop)
@@ -467,24 +510,26 @@ int csim_lu_solve_batch(int32_t device, int32_t n, int32_t B, const double* A, c
     return CSIM_OK;
 }
 
-int csim_record_pivot_schedule(csim_engine* eng, const double* d_params, int32_t B, int32_t instance,
-                               double tstep, int64_t n_steps, int32_t* pivot_pos, int64_t* n_factorizations,
-                               int64_t* n_differ)
+int csim_record_pivot_schedules(csim_engine* eng, const double* d_params, int32_t B, int32_t instance,
+                                double tstep, int64_t n_steps, int32_t max_alts, int32_t* pivot_pos,
+                                int64_t* counts, int32_t* n_alts, int64_t* n_other)
 {
-    if (!eng || !d_params || !pivot_pos || B <= 0 || instance < 0 || instance >= B || n_steps < 0 || !(tstep > 0.0)) {
-        setError("csim_record_pivot_schedule: bad argument");
+    if (!eng || !d_params || !pivot_pos || !n_alts || B <= 0 || instance < 0 || instance >= B || n_steps < 0 ||
+        !(tstep > 0.0) || max_alts <= 0) {
+        setError("csim_record_pivot_schedules: bad argument");
         return CSIM_ERR_ARG;
     }
     HIPCHK(hipSetDevice(eng->device));
     const int N = eng->plan.N;
+    const int logInts = csim::pivlog_ints(N);
     DevBuf dX, dIt32, dIt, dSt, dLog;
     HIPCHK(dX.alloc(sizeof(double) * (size_t)N * B));
     HIPCHK(dIt32.alloc(sizeof(int32_t) * (size_t)B));
     HIPCHK(dIt.alloc(sizeof(int64_t) * (size_t)B));
     HIPCHK(dSt.alloc(sizeof(uint32_t) * (size_t)B));
-    HIPCHK(dLog.alloc(sizeof(int32_t) * (size_t)(N + 2)));
+    HIPCHK(dLog.alloc(sizeof(int32_t) * (size_t)logInts));
     HIPCHK(hipMemset(dIt.p, 0, sizeof(int64_t) * (size_t)B));
-    HIPCHK(hipMemset(dLog.p, 0, sizeof(int32_t) * (size_t)(N + 2)));
+    HIPCHK(hipMemset(dLog.p, 0, sizeof(int32_t) * (size_t)logInts));
     int rc = csim_dc_batch_dev(eng, d_params, B, dX.as<double>(), dIt32.as<int32_t>(), dSt.as<uint32_t>(), nullptr);
     if (rc) return rc;
     // only the chosen instance runs (mask), with the pivot log attached
@@ -505,11 +550,46 @@ int csim_record_pivot_schedule(csim_engine* eng, const double* d_params, int32_t
                                        dLog.as<int32_t>(), instance));
     }
     HIPCHK(hipDeviceSynchronize());
-    std::vector<int32_t> log((size_t)N + 2);
+    std::vector<int32_t> log((size_t)logInts);
     HIPCHK(hipMemcpy(log.data(), dLog.p, sizeof(int32_t) * log.size(), hipMemcpyDeviceToHost));
-    for (int k = 0; k < N; ++k) pivot_pos[k] = log[(size_t)k];
-    if (n_factorizations) *n_factorizations = log[(size_t)N];
-    if (n_differ) *n_differ = log[(size_t)N + 1];
+    // most frequent first
+    std::vector<int> order;
+    for (int s2 = 0; s2 < log[0]; ++s2) order.push_back(s2);
+    auto cnt = [&](int s2) { return log[(size_t)(3 + s2 * (N + 1) + N)]; };
+    for (size_t i = 0; i < order.size(); ++i)
+        for (size_t j = i + 1; j < order.size(); ++j)
+            if (cnt(order[j]) > cnt(order[i])) std::swap(order[i], order[j]);
+    int64_t other = log[2];
+    int out = 0;
+    for (int s2 : order) {
+        if (out < max_alts) {
+            for (int k = 0; k < N; ++k) pivot_pos[(size_t)out * N + k] = log[(size_t)(3 + s2 * (N + 1) + k)];
+            if (counts) counts[out] = cnt(s2);
+            ++out;
+        } else other += cnt(s2);
+    }
+    *n_alts = out;
+    if (n_other) *n_other = other;
+    return CSIM_OK;
+}
+
+int csim_record_pivot_schedule(csim_engine* eng, const double* d_params, int32_t B, int32_t instance,
+                               double tstep, int64_t n_steps, int32_t* pivot_pos, int64_t* n_factorizations,
+                               int64_t* n_differ)
+{
+    if (!eng || !pivot_pos) { setError("csim_record_pivot_schedule: bad argument"); return CSIM_ERR_ARG; }
+    const int N = eng->plan.N;
+    std::vector<int32_t> pos((size_t)8 * N);
+    int64_t counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t nAlts = 0;
+    int64_t other = 0;
+    const int rc = csim_record_pivot_schedules(eng, d_params, B, instance, tstep, n_steps, 8, pos.data(), counts, &nAlts, &other);
+    if (rc) return rc;
+    for (int k = 0; k < N; ++k) pivot_pos[k] = nAlts > 0 ? pos[(size_t)k] : k;
+    int64_t total = other;
+    for (int a = 0; a < nAlts; ++a) total += counts[a];
+    if (n_factorizations) *n_factorizations = total;
+    if (n_differ) *n_differ = total - (nAlts > 0 ? counts[0] : 0);
     return CSIM_OK;
 }
 
@@ -518,13 +598,20 @@ int csim_engine_jit_scheduled(csim_engine* eng, const double* d_params, int32_t 
     if (!eng || !d_params || B <= 0 || !(tstep > 0.0) || plan_steps <= 0) { setError("csim_engine_jit_scheduled: bad argument"); return CSIM_ERR_ARG; }
     const csim_ir* ir = eng->cir.view();
     const int N = ir->n_unknowns;
-    std::vector<int32_t> pos((size_t)N);
-    int64_t nlu = 0, ndiff = 0;
-    int rc = csim_record_pivot_schedule(eng, d_params, B, 0, tstep, plan_steps, pos.data(), &nlu, &ndiff);
+    const int maxAlts = 4;
+    std::vector<int32_t> pos((size_t)maxAlts * N);
+    int64_t counts[maxAlts] = {0, 0, 0, 0};
+    int32_t nAlts = 0;
+    int64_t other = 0;
+    int rc = csim_record_pivot_schedules(eng, d_params, B, 0, tstep, plan_steps, maxAlts, pos.data(), counts, &nAlts, &other);
     if (rc) return rc;
-    if (nlu == 0) { setError("planner saw no factorisation"); return CSIM_ERR_UNSUPPORTED; }
-    csim::PivotSchedule sch = csim::PivotSchedule::identity(N);
-    for (int k = 0; k < N; ++k) sch.pivotPos[(size_t)k] = pos[(size_t)k];
+    if (nAlts == 0) { setError("planner saw no successful factorisation"); return CSIM_ERR_UNSUPPORTED; }
+    csim::ScheduleSet sch;
+    for (int a = 0; a < nAlts; ++a) {
+        csim::PivotSchedule one = csim::PivotSchedule::identity(N);
+        for (int k = 0; k < N; ++k) one.pivotPos[(size_t)k] = pos[(size_t)a * N + k];
+        sch.alts.push_back(one);
+    }
 
     const unsigned long long topo = csim::scheduleHash(*ir, csim::PivotSchedule::identity(N));
     const unsigned long long full = csim::scheduleHash(*ir, sch);
@@ -565,6 +652,7 @@ int csim_engine_jit_scheduled(csim_engine* eng, const double* d_params, int32_t 
     eng->schedLib = handle;
     eng->schedLaunch = launch;
     eng->schedInfo = infoFn ? infoFn() : "";
+    adoptScheduleTable(eng, handle);
     return CSIM_OK;
 }
 

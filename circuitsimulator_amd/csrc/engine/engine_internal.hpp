@@ -29,11 +29,14 @@ struct csim_engine {
 
     // circuit-specialised transient kernel (side library libcsim_sched_<topology>.so)
     typedef int (*SchedLaunchFn)(const double*, int, double, long long, long long, const int*, int, int,
-                                 double*, double*, long long*, unsigned*, int*, unsigned char*, void*, int);
+                                 double*, double*, long long*, unsigned*, int*, unsigned char*, int*, void*, int);
     void* schedLib = nullptr;
     SchedLaunchFn schedLaunch = nullptr;
     std::string schedInfo;
-    unsigned char* dFallback = nullptr;    // per-instance "re-run with the general kernel" mask
+    int32_t* dKnownAlts = nullptr;         // [nKnownAlts][N] pivot sequences the loaded kernel carries
+    int nKnownAlts = 0;
+    unsigned char* dFallback = nullptr;    // per-instance "a schedule check failed in this launch" mask
+    int32_t* dDone = nullptr;              // per-instance steps of the current launch already completed
     int fallbackCap = 0;
 
     // large circuits (N > 63): dense scratch matrices in global memory, one per instance

@@ -15,7 +15,9 @@ hipError_t launchTranGeneral(const GenPlan& pl, const double* dParams, int B, do
                              long long stepFirst, long long nSteps, const int32_t* dProbeEq, int nProbe,
                              int outStride, double* dWave, double* dX, long long* dIters,
                              uint32_t* dStatus, int32_t* dStepIters, const uint8_t* dOnly,
-                             hipStream_t stream, int32_t* dPivLog = nullptr, int pivInstance = -1);
+                             hipStream_t stream, int32_t* dPivLog = nullptr, int pivInstance = -1,
+                             int32_t* dDone = nullptr, int maxSteps = 0,
+                             const int32_t* dKnownAlts = nullptr, int nKnown = 0);
 hipError_t launchLuSolve(int n, int B, const double* dA, const double* dRhs, double* dX,
                          uint32_t* dFlags, double eps, hipStream_t stream);
 hipError_t launchLuFactor(int n, int B, const double* dA, double* dLU, int32_t* dPerm, uint32_t* dFlags,
@@ -31,7 +33,7 @@ hipError_t launchTranBig(const GenPlan& pl, const double* dParams, int B, double
                          long long nSteps, const int32_t* dProbeEq, int nProbe, int outStride, double* dWave,
                          double* dX, long long* dIters, uint32_t* dStatus, int32_t* dStepIters,
                          const uint8_t* dOnly, double* dScratch, const int32_t* dSlotOf, hipStream_t stream,
-                         int32_t* dPivLog = nullptr, int pivInstance = -1);
+                         int32_t* dPivLog = nullptr, int pivInstance = -1, int32_t* dDone = nullptr, int maxSteps = 0);
 
 // Monte-Carlo parameter table (mc.hip)
 hipError_t launchMcParams(int P, int B, long long bFirst, uint64_t seed, double sigma,

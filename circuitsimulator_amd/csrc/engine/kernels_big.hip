@@ -131,8 +131,7 @@ __device__ __forceinline__ void lu_solve_big(const GenPlan& pl, const BigLds& L,
                                              int lane, unsigned& flags, int32_t* pivLog)
 {
     const int N = pl.N, LD = pl.LD;
-    const bool logFirst = pivLog && pivLog[N] == 0;
-    bool logDiffer = false;
+    int32_t* const logCur = pivLog ? pivlog_cur(pivLog, N) : nullptr;
     bool failed = false;
 
     for (int k = 0; k < N && !failed; ++k) {
@@ -177,10 +176,7 @@ __device__ __forceinline__ void lu_solve_big(const GenPlan& pl, const BigLds& L,
         }
         if (nCand > 64) { flags |= CSIM_ST_LU_TINY_PIVOT; failed = true; break; }   // > 64 rows in one column: not this kernel
         if (maxAbs < eps) { failed = true; break; }
-        if (pivLog) {
-            if (logFirst) { if (lane == 0) pivLog[k] = piv; }
-            else if (pivLog[k] != piv) logDiffer = true;
-        }
+        if (logCur && lane == 0) logCur[k] = piv;
         wave_sync();
         // ---- logical swap of positions k and piv
         const int rowK = L.rowOf[piv];          // physical row that becomes the pivot row
@@ -222,10 +218,7 @@ __device__ __forceinline__ void lu_solve_big(const GenPlan& pl, const BigLds& L,
         wave_sync();
     }
 
-    if (pivLog && lane == 0) {
-        pivLog[N] += 1;
-        if (logDiffer || (failed && !logFirst)) pivLog[N + 1] += 1;
-    }
+    if (pivLog) pivlog_commit(pivLog, N, failed, lane);
     if (failed) {
         flags |= CSIM_ST_LU_TINY_PIVOT;
         for (int i = lane; i < N; i += 64) L.xr[i] = 0.0;
@@ -363,12 +356,16 @@ k_tran_big(GenPlan pl, const double* __restrict__ params, int B, double dt, long
            const int32_t* __restrict__ probeEq, int nProbe, int outStride, double* __restrict__ wave,
            double* __restrict__ xio, long long* __restrict__ iters, uint32_t* __restrict__ status,
            int32_t* __restrict__ stepIters, const uint8_t* __restrict__ only, double* __restrict__ scratch,
-           const int32_t* __restrict__ slotOf, int32_t* __restrict__ pivLog, int pivInstance)
+           const int32_t* __restrict__ slotOf, int32_t* __restrict__ pivLog, int pivInstance,
+           int32_t* __restrict__ done, int maxSteps)
 {
     extern __shared__ unsigned char smraw[];
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     if (only && !only[b]) return;
+    const long long d0 = done ? (long long)done[b] : 0;        // hybrid stepping, see kernels_general.hip
+    if (done && d0 >= nSteps) return;
+    const long long sEnd = done ? (d0 + maxSteps < nSteps ? d0 + maxSteps : nSteps) : nSteps;
     const int N = pl.N;
     const BigLds L = carve(smraw, N, pl.nTerms, pl.P);
     // scratch matrices are handed out per running instance: slotOf maps instance -> slot
@@ -385,15 +382,15 @@ k_tran_big(GenPlan pl, const double* __restrict__ params, int B, double dt, long
     if (lane == 0) L.T[pl.termGmin] = K.tran_gmin;
     wave_sync();
 
-    if (stepFirst == 0 && wave)
+    if (stepFirst == 0 && d0 == 0 && wave)
         for (int q = lane; q < nProbe; q += 64) wave[((int64_t)0 * nProbe + q) * B + b] = L.xs[probeEq[q]];
 
     unsigned st = (status[b] & CSIM_ST_TRAN_NONFINITE);
-    if (only) st |= CSIM_ST_SCHED_FALLBACK;
+    if (done) st |= CSIM_ST_SCHED_FALLBACK;
     long long itTotal = 0;
     bool aborted = (st & CSIM_ST_TRAN_NONFINITE) != 0;
 
-    for (long long s = 1; s <= nSteps && !aborted; ++s) {
+    for (long long s = d0 + 1; s <= sEnd && !aborted; ++s) {
         const long long gstep = stepFirst + s;
         const double tNow = (double)(int)gstep * dt;
         terms_step_tran(pl, L.Pv, L.T, L.xp, tNow, lane);
@@ -438,7 +435,11 @@ k_tran_big(GenPlan pl, const double* __restrict__ params, int B, double dt, long
     }
 
     for (int i = lane; i < N; i += 64) xio[(int64_t)i * B + b] = L.xs[i];
-    if (lane == 0) { iters[b] += itTotal; status[b] |= st; }
+    if (lane == 0) {
+        iters[b] += itTotal;
+        status[b] |= st;
+        if (done) done[b] = aborted ? (int32_t)nSteps : (int32_t)sEnd;
+    }
 }
 
 // ------------------------------------------------------------------ launchers
@@ -459,14 +460,14 @@ hipError_t launchTranBig(const GenPlan& pl, const double* dParams, int B, double
                          long long nSteps, const int32_t* dProbeEq, int nProbe, int outStride, double* dWave,
                          double* dX, long long* dIters, uint32_t* dStatus, int32_t* dStepIters,
                          const uint8_t* dOnly, double* dScratch, const int32_t* dSlotOf, hipStream_t stream,
-                         int32_t* dPivLog, int pivInstance)
+                         int32_t* dPivLog, int pivInstance, int32_t* dDone, int maxSteps)
 {
     const size_t lds = bigLdsBytes(pl.N, pl.nTerms, pl.P);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tran_big), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_tran_big, dim3(B), dim3(64), lds, stream, pl, dParams, B, dt, stepFirst, nSteps, dProbeEq,
                        nProbe, outStride, dWave, dX, dIters, dStatus, dStepIters, dOnly, dScratch, dSlotOf, dPivLog,
-                       pivInstance);
+                       pivInstance, dDone, maxSteps);
     return hipGetLastError();
 }
 

@@ -129,12 +129,18 @@ k_tran_general(GenPlan pl, const double* __restrict__ params, int B, double dt,
                double* __restrict__ wave, double* __restrict__ xio,
                long long* __restrict__ iters, uint32_t* __restrict__ status,
                int32_t* __restrict__ stepIters, const uint8_t* __restrict__ only,
-               int32_t* __restrict__ pivLog, int pivInstance)
+               int32_t* __restrict__ pivLog, int pivInstance, int32_t* __restrict__ done, int maxSteps,
+               const int32_t* __restrict__ knownAlts, int nKnown)
 {
     extern __shared__ double sm[];
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
-    if (only && !only[b]) return;           // fallback launches touch flagged instances only
+    if (only && !only[b]) return;           // planner launches touch the chosen instance only
+    // hybrid stepping: `done` = steps of this launch each instance has completed; this kernel
+    // advances an unfinished instance by at most maxSteps and hands it back
+    const long long d0 = done ? (long long)done[b] : 0;
+    if (done && d0 >= nSteps) return;
+    const long long sEnd = done ? (d0 + maxSteps < nSteps ? d0 + maxSteps : nSteps) : nSteps;
     int32_t* myPivLog = (pivLog && b == pivInstance) ? pivLog : nullptr;
     const int N = pl.N, LD = pl.LD;
     const LdsLayout L = ldsLayout(N, LD, pl.nTerms, pl.P);
@@ -144,6 +150,7 @@ k_tran_general(GenPlan pl, const double* __restrict__ params, int B, double dt,
     double* xs = sm + L.xs;
     double* xp = sm + L.xp;
     double* sc = sm + L.sc;
+    int32_t* curPiv = (done && knownAlts) ? reinterpret_cast<int32_t*>(sm + L.piv) : nullptr;
     const csim_consts& K = pl.k;
 
     for (int p = lane; p < pl.P; p += 64) Pv[p] = params[(int64_t)p * B + b];
@@ -158,15 +165,18 @@ k_tran_general(GenPlan pl, const double* __restrict__ params, int B, double dt,
     if (lane == 0) T[pl.termGmin] = K.tran_gmin;
     wave_sync();
 
-    if (stepFirst == 0 && wave)                     // t = 0 row (:250)
+    if (stepFirst == 0 && d0 == 0 && wave)          // t = 0 row (:250)
         for (int q = lane; q < nProbe; q += 64) wave[((int64_t)0 * nProbe + q) * B + b] = xs[probeEq[q]];
 
     unsigned st = (status[b] & CSIM_ST_TRAN_NONFINITE);
-    if (only) st |= CSIM_ST_SCHED_FALLBACK;
+    if (done) st |= CSIM_ST_SCHED_FALLBACK;
     long long itTotal = 0;
     bool aborted = (st & CSIM_ST_TRAN_NONFINITE) != 0;                 // an instance the reference would have thrown on stays stopped
 
-    for (long long s = 1; s <= nSteps && !aborted; ++s) {
+    long long sLast = d0;
+    for (long long s = d0 + 1; s <= sEnd && !aborted; ++s) {
+        sLast = s;
+        bool stepKnown = curPiv != nullptr;     // every factorisation of this step on a known sequence?
         const long long gstep = stepFirst + s;
         const double tNow = (double)(int)gstep * dt;                    // :256
         terms_step_tran(pl, Pv, T, xp, tNow, lane);
@@ -176,7 +186,8 @@ k_tran_general(GenPlan pl, const double* __restrict__ params, int B, double dt,
             terms_iter_mos(pl, Pv, T, xs, lane);
             wave_sync();
             assemble(pl, T, Gm, lane);                                  // :259-356
-            const double xr = lu_solve_wave(Gm, N, LD, K.lu_eps, lane, st, myPivLog);   // :359
+            const double xr = lu_solve_wave(Gm, N, LD, K.lu_eps, lane, st, myPivLog, curPiv);   // :359
+            if (stepKnown) stepKnown = sequence_is_known(curPiv, knownAlts, nKnown, N, lane);
             ++it;
             if (!wave_all_finite(xr, N, lane)) {                        // :360-362
                 st |= CSIM_ST_TRAN_NONFINITE;
@@ -199,12 +210,14 @@ k_tran_general(GenPlan pl, const double* __restrict__ params, int B, double dt,
         if (wave && (gstep % outStride) == 0)                           // :419
             for (int q = lane; q < nProbe; q += 64)
                 wave[((gstep / outStride) * nProbe + q) * (int64_t)B + b] = xs[probeEq[q]];
+        if (stepKnown) break;                   // back on a recorded schedule: hand the instance back
     }
 
     if (lane < N) xio[(int64_t)lane * B + b] = xs[lane];
     if (lane == 0) {
         iters[b] += itTotal;
         status[b] |= st;
+        if (done) done[b] = aborted ? (int32_t)nSteps : (int32_t)sLast;
     }
 }
 
@@ -269,12 +282,13 @@ hipError_t launchTranGeneral(const GenPlan& pl, const double* dParams, int B, do
                              long long stepFirst, long long nSteps, const int32_t* dProbeEq, int nProbe,
                              int outStride, double* dWave, double* dX, long long* dIters,
                              uint32_t* dStatus, int32_t* dStepIters, const uint8_t* dOnly,
-                             hipStream_t stream, int32_t* dPivLog, int pivInstance)
+                             hipStream_t stream, int32_t* dPivLog, int pivInstance, int32_t* dDone, int maxSteps,
+                             const int32_t* dKnownAlts, int nKnown)
 {
     const LdsLayout L = ldsLayout(pl.N, pl.LD, pl.nTerms, pl.P);
     const size_t lds = sizeof(double) * (size_t)L.total;
     hipLaunchKernelGGL(k_tran_general, dim3(B), dim3(64), lds, stream, pl, dParams, B, dt, stepFirst, nSteps,
-                       dProbeEq, nProbe, outStride, dWave, dX, dIters, dStatus, dStepIters, dOnly, dPivLog, pivInstance);
+                       dProbeEq, nProbe, outStride, dWave, dX, dIters, dStatus, dStepIters, dOnly, dPivLog, pivInstance, dDone, maxSteps, dKnownAlts, nKnown);
     return hipGetLastError();
 }
 

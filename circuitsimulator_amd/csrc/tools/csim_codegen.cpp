@@ -21,15 +21,11 @@
 
 static std::string readSchedule(const std::string& path)
 {
-    if (path == "-") return "";
+    if (path == "-") return "-";
     std::ifstream f(path);
     if (!f) { std::cerr << "cannot open schedule file " << path << "\n"; std::exit(2); }
     std::string line, all;
-    while (std::getline(f, line)) {
-        const std::size_t hashAt = line.find('#');
-        if (hashAt != std::string::npos) line = line.substr(0, hashAt);
-        all += line + ",";
-    }
+    while (std::getline(f, line)) all += line + "\n";      // one schedule per line; '#' comments
     return all;
 }
 
@@ -51,8 +47,8 @@ int main(int argc, char** argv)
     const csim::CircuitIR cir = csim::flatten(ckt);
     const csim_ir* ir = cir.view();
     const csim::AssemblyPlan ap = csim::buildAssemblyPlan(*ir);
-    csim::PivotSchedule sch;
-    if (!csim::PivotSchedule::parse(readSchedule(schedPath), ir->n_unknowns, sch)) {
+    csim::ScheduleSet sch;
+    if (!csim::ScheduleSet::parse(readSchedule(schedPath), ir->n_unknowns, sch)) {
         std::cerr << "bad schedule\n";
         return 2;
     }
@@ -70,7 +66,7 @@ int main(int argc, char** argv)
     std::ofstream out(argv[3]);
     if (!out) { std::cerr << "cannot write " << argv[3] << "\n"; return 2; }
     out << src;
-    std::fprintf(stderr, "csim_codegen: %s N=%d hash=%016llx  per NR iteration: fma=%d mul=%d add/sub=%d recip=%d "
+    std::fprintf(stderr, "csim_codegen: %s N=%d hash=%016llx  first schedule, per NR iteration: fma=%d mul=%d add/sub=%d recip=%d "
                          "cmp=%d  L entries=%d dynamic U entries=%d\n",
                  label.c_str(), ir->n_unknowns, h, st.nFma, st.nMul, st.nAddSub, st.nRecip, st.nCmp, st.nLower, st.nDynU);
     std::printf("%016llx\n", topo);

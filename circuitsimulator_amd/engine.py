@@ -241,6 +241,22 @@ class Engine:
         sched = ",".join("%d:%d" % (k, p) for k, p in enumerate(pos) if p != k)
         return sched, nlu.value, ndiff.value
 
+    def record_pivot_schedules(self, params, instance=0, tstep=None, n_steps=200, max_alts=8):
+        """Planner: every distinct pivot sequence of one instance's transient factorisations,
+        most frequent first: ([(schedule string, count), ...], n_other)."""
+        tstep = self.netlist.tstep if tstep is None else tstep
+        pos = np.zeros((max_alts, self.N), dtype=np.int32)
+        counts = np.zeros(max_alts, dtype=np.int64)
+        n_alts, other = C.c_int32(), C.c_int64()
+        capi.check(capi.lib().csim_record_pivot_schedules(self._h, params.data_ptr(), params.shape[1], instance,
+                                                          float(tstep), int(n_steps), max_alts, pos.ctypes.data,
+                                                          counts.ctypes.data, C.byref(n_alts), C.byref(other)))
+        out = []
+        for a in range(n_alts.value):
+            sched = ",".join("%d:%d" % (k, p) for k, p in enumerate(pos[a]) if p != k) or "-"
+            out.append((sched, int(counts[a])))
+        return out, other.value
+
     def close(self):
         if self._h:
             capi.lib().csim_engine_destroy(self._h)

@@ -167,6 +167,7 @@ int  csim_lu_solve_batch(int32_t device, int32_t n, int32_t B, const double* A,
 /* Runtime specialisation for a netlist without a prebuilt libcsim_sched_<topology>.so:
  * records the pivot schedule of instance 0 of d_params with the general kernel
  * (plan_steps transient steps), generates the lane-per-instance kernel, compiles it
+ * (up to 4 distinct sequences seen while planning become alternatives), compiles it
  * with hipcc (--offload-arch=gfx950; $CSIM_HIPCC overrides the compiler path) into
  * $CSIM_JIT_DIR (default /tmp/csim_jit) and loads it.  A cached library of the same
  * (topology, constants, schedule) hash is reused.  After CSIM_OK,
@@ -189,6 +190,13 @@ int  csim_lu_decompose_batch(int32_t device, int32_t n, int32_t B, const double*
 int  csim_record_pivot_schedule(csim_engine* eng, const double* d_params /*[P][B]*/, int32_t B,
                                 int32_t instance, double tstep, int64_t n_steps,
                                 int32_t* pivot_pos, int64_t* n_factorizations, int64_t* n_differ);
+/* Same run, every DISTINCT sequence seen (at most 8, most frequent first): pivot_pos
+ * [max_alts][N], counts [max_alts] = factorisations that used each, *n_alts = how many were
+ * found, *n_other = factorisations that failed or used a sequence beyond the eighth.  A
+ * switching circuit alternates between a few sequences; a schedule file may list several. */
+int  csim_record_pivot_schedules(csim_engine* eng, const double* d_params /*[P][B]*/, int32_t B,
+                                 int32_t instance, double tstep, int64_t n_steps, int32_t max_alts,
+                                 int32_t* pivot_pos, int64_t* counts, int32_t* n_alts, int64_t* n_other);
 
 #ifdef __cplusplus
 }

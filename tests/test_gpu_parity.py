@@ -192,26 +192,61 @@ def test_scheduled_equals_general_on_mc_batch(engines, torch_mod):
     assert rel_err(fast["x"].T, slow["x"].T, nl.n_node_eq).max() < TOL
 
 
-def test_schedule_violation_falls_back_and_stays_correct(engines, torch_mod):
-    """buffer.sp at its shipped time step switches between 5 pivot sequences (the recorded one
-    is the single sequence of the 10k-step run): the per-factorisation check must catch it, the
-    instance must be re-run by the general kernel and flagged, and results must still match."""
+def test_switching_circuit_alternatives_and_hybrid_stepping(engines, torch_mod):
+    """buffer.sp at its shipped 1 ns step switches hard and alternates between several pivot
+    sequences (7 recorded alternatives in schedules/buffer.sched).  Every factorisation verifies
+    the alternative it uses; a factorisation no alternative fits makes the scheduled kernel
+    checkpoint the step and hand the instance to the general kernel, which returns it once a
+    whole step ran on recorded sequences again.  Whatever the path, results must match."""
     nl, eng = engines["buffer"]
-    B = 8
+    B = 512
     params = eng.mc_params(12345, 0.05, 0, B)
-    r = _run_tran(torch_mod, eng, params, 300, nl.tstep, want_step_iters=True)
-    assert (r["status"] & FALLBACK).all()
+    eng.set_kernel("general")
+    slow = _run_tran(torch_mod, eng, params, 300, nl.tstep, want_step_iters=True)
+    eng.set_kernel("auto")
+    fast = _run_tran(torch_mod, eng, params, 300, nl.tstep, want_step_iters=True, chunks=[120, 180])
+    assert np.array_equal(fast["step_iters"], slow["step_iters"])
+    assert np.array_equal(fast["iters"], slow["iters"])
+    assert np.array_equal(fast["status"] & NOFB, slow["status"])
+    assert rel_err(fast["x"].T, slow["x"].T, nl.n_node_eq).max() < TOL
+    n_fb = int(((fast["status"] & FALLBACK) != 0).sum())
+    assert n_fb < B // 4                      # the recorded alternatives cover almost every instance
     ph = params.cpu().numpy()
-    for b in (0, 3, B - 1):
-        o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstop, want_rows=False, want_step_iters=True)
-        assert r["iters"][b] == o["iters"] and np.array_equal(r["step_iters"][:, b], o["step_iters"])
-        assert rel_err(r["x"][:, b], o["x_final"], nl.n_node_eq).max() < TOL
-    # at 3e-11 s the recorded schedule holds for every factorisation: no fallback
-    r = _run_tran(torch_mod, eng, params, 2000, 3e-11)
+    flagged = np.where((fast["status"] & FALLBACK) != 0)[0]
+    for b in [0, 3, B - 1] + list(flagged[:2]):
+        o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, int(b), nl.tstep, nl.tstop, want_rows=False, want_step_iters=True)
+        assert fast["iters"][b] == o["iters"] and np.array_equal(fast["step_iters"][:, b], o["step_iters"])
+        assert rel_err(fast["x"][:, b], o["x_final"], nl.n_node_eq).max() < TOL
+    # at 3e-11 s the first alternative holds for every factorisation: no hand-over at all
+    r = _run_tran(torch_mod, eng, params[:, :8].contiguous(), 2000, 3e-11)
     assert not (r["status"] & FALLBACK).any()
     o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, 1, 3e-11, 3e-11 * 2000, want_rows=False)
     assert r["iters"][1] == o["iters"]
     assert rel_err(r["x"][:, 1], o["x_final"], nl.n_node_eq).max() < TOL
+
+
+def test_hybrid_stepping_when_no_alternative_fits(torch_mod, tmp_path, monkeypatch):
+    """Force the hand-over path: JIT a kernel from a plan that saw only the quiet start of a
+    switching circuit, then run through the switching; flagged instances must still be exact."""
+    import shutil, os
+    from circuitsimulator_amd import Engine, Netlist
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available for the JIT")
+    monkeypatch.setenv("CSIM_JIT_DIR", str(tmp_path / "jit"))
+    text = open(netlist_path("buffer.sp")).read().replace("Rin 101 102 10", "Rin 101 102 11")   # new topology hash? no: new constants only
+    nl = Netlist.from_text(text + "\nRextra 118 0 1e9\n")          # one more element: no prebuilt kernel
+    eng = Engine(nl, 0)
+    assert eng.tran_kernel == "general"
+    B = 64
+    params = eng.mc_params(5, 0.05, 0, B)
+    slow = _run_tran(torch_mod, eng, params, 300, nl.tstep, want_step_iters=True)
+    eng.jit_scheduled(params, plan_steps=3)                          # 3 quiet steps: one sequence only
+    assert eng.tran_kernel == "scheduled"
+    fast = _run_tran(torch_mod, eng, params, 300, nl.tstep, want_step_iters=True)
+    assert ((fast["status"] & FALLBACK) != 0).any()                  # the hand-over really happened
+    assert np.array_equal(fast["step_iters"], slow["step_iters"])
+    assert np.array_equal(fast["status"] & NOFB, slow["status"])
+    assert rel_err(fast["x"].T, slow["x"].T, nl.n_node_eq).max() < TOL
 
 
 def test_scheduled_kernel_ragged_batch(engines, torch_mod):
@@ -418,26 +453,30 @@ def test_cli_writes_the_reference_csv(tmp_path, buffer_nl):
 
 
 def test_committed_schedules_match_the_planner(engines, torch_mod):
-    """csrc/schedules/*.sched are what the general kernel's planner records on this GPU, and equal
-    SURVEY.md Appendix F; dbmixer keeps one sequence through the run, also under MC perturbation."""
+    """csrc/schedules/*.sched are what the general kernel's planner records on this GPU, and their
+    first lines equal SURVEY.md Appendix F; dbmixer keeps ONE sequence through the run, also under
+    MC perturbation; buffer at its shipped 1 ns step alternates between the committed ones."""
     import os
     from conftest import ROOT
 
     def committed(name):
         txt = open(os.path.join(ROOT, "circuitsimulator_amd", "csrc", "schedules", name + ".sched")).read()
-        return ",".join(l.strip() for l in txt.splitlines() if l.strip() and not l.startswith("#"))
+        return [l.split("#")[0].strip() for l in txt.splitlines() if l.split("#")[0].strip()]
 
     nl, eng = engines["dbmixer"]
     params = eng.mc_params(12345, 0.05, 0, 4)
+    assert len(committed("dbmixer")) == 1
     for b in range(4):
         sched, nlu, ndiff = eng.record_pivot_schedule(params, b, None, 1500)
-        assert sched == committed("dbmixer") and ndiff == 0 and nlu > 10000
+        assert sched == committed("dbmixer")[0] and ndiff == 0 and nlu > 10000
     nl, eng = engines["buffer"]
     params = eng.mc_params(12345, 0.05, 0, 2)
     sched, nlu, ndiff = eng.record_pivot_schedule(params, 0, 3e-11, 3000)
-    assert sched == committed("buffer") and ndiff == 0
-    sched, nlu, ndiff = eng.record_pivot_schedule(params, 0, 1e-9, 300)     # as shipped: several sequences
-    assert ndiff > 0
+    assert sched == committed("buffer")[0] and ndiff == 0
+    alts, other = eng.record_pivot_schedules(params, 0, 1e-9, 300)       # as shipped: several sequences
+    assert len(alts) >= 4 and other == 0
+    assert alts[0][0] == committed("buffer")[0]
+    assert all(a in committed("buffer") for a, _ in alts)
 
 
 INVERTER_CHAIN = """* three CMOS inverters driving an RC line (not one of the shipped netlists)

@@ -3,9 +3,9 @@
 
     python tools/record_schedule.py tests/golden/dbmixer.sp [--steps 2000] [--tstep 1e-13] [--mc 16]
 
-Prints the "column:row,..." line that goes into circuitsimulator_amd/csrc/schedules/<name>.sched and how
-stable it is: the number of factorisations seen and how many chose another sequence, for the nominal
-circuit and for a few Monte-Carlo instances.  The schedule is verified again at run time on every
+Prints every distinct "column:row,..." sequence with how many factorisations used it, for the nominal
+circuit and a few Monte-Carlo instances, and the body of circuitsimulator_amd/csrc/schedules/<name>.sched
+(one alternative per line, most frequent first).  The schedule is verified again at run time on every
 factorisation, so this only decides how often the fast kernel is used, never what it computes.
 """
 import argparse
@@ -26,14 +26,16 @@ def main():
     nl = Netlist.from_file(a.netlist)
     eng = Engine(nl, 0)
     params = eng.mc_params(12345, 0.05, 0, max(1, a.mc))
-    first = None
+    total = {}
     for b in range(max(1, a.mc)):
-        sched, nlu, ndiff = eng.record_pivot_schedule(params, b, a.tstep, a.steps)
-        if first is None:
-            first = sched
-            print("schedule (nominal instance): %s" % (sched or "-"))
-        print("instance %3d: %8d factorisations, %6d with another sequence%s"
-              % (b, nlu, ndiff, "" if sched == first else "   FIRST SEQUENCE DIFFERS: " + sched))
+        alts, other = eng.record_pivot_schedules(params, b, a.tstep, a.steps)
+        print("instance %3d: %s%s" % (b, "  ".join("[%s] x%d" % sc for sc in alts),
+                                      ("  other/failed x%d" % other) if other else ""))
+        for sched, n in alts:
+            total[sched] = total.get(sched, 0) + n
+    print("\n# schedule file body (most frequent first; one alternative per line):")
+    for sched, n in sorted(total.items(), key=lambda kv: -kv[1]):
+        print("%s    # %d factorisations" % (sched, n))
 
 
 if __name__ == "__main__":
