@@ -105,7 +105,7 @@ uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch)
         for (std::size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
     };
     auto mixInt = [&](int32_t v) { mixBytes(&v, sizeof v); };
-    mixInt(5);                                            // generator revision
+    mixInt(9);                                            // generator revision
     mixInt(ir.n_unknowns); mixInt(ir.n_node_eq); mixInt(ir.n_branch_eq);
     mixInt(ir.n_elems); mixInt(ir.n_params); mixInt(ir.has_nonlinear);
     for (int e = 0; e < ir.n_elems; ++e) {
@@ -377,7 +377,9 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         << "    const bool inb = b < B;\n"
         << "    const long long bb = inb ? b : B - 1;      // out-of-range lanes shadow the last instance, never store\n"
         << "    const long long SB = B;\n"
-        << "    const bool splitFlag = outStride < 0;      // never true (the engine rejects it); opaque to the compiler\n";
+        << "    const bool splitFlag = outStride < 0;      // never true (the engine rejects it); opaque to the compiler\n"
+        << "    // hand-back launches: nothing to do for this wave unless one of its instances is unfinished\n"
+        << "    if (!__any(inb && done[bb] < nSteps)) return;\n";
 
     // ---- parameters
     for (int p = 0; p < ir.n_params; ++p) {
@@ -412,7 +414,8 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
     src << ldsInit.str();
 
     // ---- state
-    for (int i = 0; i < N; ++i) src << "    X(" << i << ") = xio[" << i << "LL * SB + bb];\n";
+    src << "    {\n        const double* xin = xio + bb;\n#pragma unroll 1\n"
+        << "        for (int i = 0; i < " << N << "; ++i, xin += SB) X(i) = *xin;\n    }\n";
     src << "    unsigned st = inb ? status[bb] : 0u;\n"
         << "    bool dead = !inb || (st & ST_TRAN_NONFINITE) != 0u;   // the reference would have thrown: stay stopped\n"
         << "    long long itTotal = 0;\n"
@@ -422,15 +425,23 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         << "    if (stepFirst == 0 && sdone == 0 && wave && inb) {\n"
         << "        for (int q = 0; q < nProbe; ++q) wave[((long long)q) * SB + b] = X(probeEq[q]);\n"
         << "    }\n\n"
-        << "    for (;;) {\n"
-        << "        const bool live = !dead && !viol && sdone < nSteps;\n"
-        << "        if (!__any(live)) break;\n"
-        << "        const long long s = sdone + 1;              // per lane: lanes of a wave may be at different steps\n"
+        << "    // the step counter stays wave-uniform (scalar registers): start at the least advanced lane's next\n"
+        << "    // step; a lane takes part in step s when s is ITS next step (lanes handed back by the general\n"
+        << "    // kernel may be ahead of or behind their wave-mates)\n"
+        << "    int smin = (int)(sdone < nSteps ? sdone + 1 : nSteps + 1);\n"
+        << "    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(smin, m); smin = o < smin ? o : smin; }\n"
+        << "    smin = __builtin_amdgcn_readfirstlane(smin);\n"
+        << "    for (long long s = smin; s <= nSteps; ++s) {\n"
+        << "        if (!__any(!dead && !viol && sdone < nSteps)) break;\n"
+        << "        const bool live = !dead && !viol && sdone + 1 == s;\n"
         << "        const long long gstep = stepFirst + s;\n"
         << "        const double tNow = (double)(int)gstep * dt;\n"
-        << "        if (live) {                                 // checkpoint: state at the start of this step\n";
-    for (int i = 0; i < N; ++i) src << "            xio[" << i << "LL * SB + b] = X(" << i << ");\n";
-    src << "        }\n";
+        << "        if (live) {     // checkpoint: state at the start of this step.  A ROLLED loop: unrolled,\n"
+        << "                        // hipcc hoists the N store addresses out of the time loop and pins 2N VGPRs\n"
+        << "            double* ck = xio + b;\n"
+        << "#pragma unroll 1\n"
+        << "            for (int i = 0; i < " << N << "; ++i, ck += SB) *ck = X(i);\n"
+        << "        }\n";
 
     // ---- per-step terms (device_common.hpp terms_step_tran), stored to LDS or kept in registers
     const std::string i2 = "        ";
@@ -573,14 +584,18 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             const int p = sc.pivotPos[static_cast<std::size_t>(k)];
             const AV ap_ = at(p, k);
             g.out << g.ind << "// column " << k << ": pivot row position " << p << "\n";
-            // Tuning knob (off by default): a basic-block boundary every CSIM_CG_SPLIT columns through a
-            // scalar branch on an opaque, never-true flag.  hipcc schedules each basic block for ILP and
-            // inflates the live set of this 3000-instruction body; the short-circuit "pv = pv || ..."
-            // chains below already split it (turning them into branch-free "|=" was measured 37 %
-            // slower: 6.5e8 -> 4.1e8), extra boundaries were measured neutral (6.3e8).
-            if (splitEvery > 0 && (k % splitEvery) == 0)
-                g.out << g.ind << "if (splitFlag) asm volatile(\"s_nop 0\");\n";
-            // the reference picks the FIRST row attaining the column maximum (solver.hpp:48-56)
+            // A scheduling barrier per column.  hipcc schedules each basic block for ILP and inflates the
+        // live set of this 3000-instruction body; with the barrier the allocator ends at 86 spilled
+        // registers, without it at ~200 (measured 6.5e8 vs 5.1e8 NR-iter*inst/s at B = 4096).  The
+        // short-circuit "pv = pv || ..." chains below split blocks to the same effect (branch-free
+        // "|=" was measured 37 % slower).  CSIM_CG_SPLIT=n swaps the barrier for a real block boundary
+        // (scalar branch on an opaque never-true flag) every n columns: measured equal within noise.
+        if (splitEvery > 0) {
+            if ((k % splitEvery) == 0) g.out << g.ind << "if (splitFlag) asm volatile(\"s_nop 0\");\n";
+        } else if (std::getenv("CSIM_CG_NOBARRIER") == nullptr) {
+            g.out << g.ind << "__builtin_amdgcn_sched_barrier(0);\n";
+        }
+        // the reference picks the FIRST row attaining the column maximum (solver.hpp:48-56)
             // and fails below 1e-15 (:58-61)
             if (ap_.isZero()) {
                 g.out << g.ind << pvName << " = true;   // scheduled pivot is a structural zero\n";
@@ -728,8 +743,9 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         << "    if (inb) {\n"
         << "        if (viol) fallback[b] = 1;               // xio holds the checkpoint of the step that failed\n"
         << "        else {\n";
-    for (int i = 0; i < N; ++i) src << "            xio[" << i << "LL * SB + b] = X(" << i << ");\n";
-    src << "        }\n"
+    src << "            double* xo = xio + b;\n#pragma unroll 1\n"
+        << "            for (int i = 0; i < " << N << "; ++i, xo += SB) *xo = X(i);\n"
+        << "        }\n"
         << "        iters[b] += itTotal;\n"
         << "        status[b] |= st;\n"
         << "        done[b] = (int)sdone;\n"

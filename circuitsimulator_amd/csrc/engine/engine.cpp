@@ -299,7 +299,8 @@ int csim_tran_batch_dev(csim_engine* eng, const double* d_params, int32_t B, dou
     }
     hipStream_t hs = static_cast<hipStream_t>(stream);
     const int np = d_wave ? n_probe : 0, os = d_wave ? out_stride : 1;
-    auto general = [&](int32_t* dDone, int maxSteps) -> int {
+    // handBack: stop an instance after the first step that ran on recorded sequences only
+    auto general = [&](int32_t* dDone, int maxSteps, bool handBack = false) -> int {
         if (eng->big) {
             const int rc = ensureBigScratch(eng, B, hs);
             if (rc) return rc;
@@ -309,8 +310,8 @@ int csim_tran_batch_dev(csim_engine* eng, const double* d_params, int32_t B, dou
         } else {
             HIPCHK(csim::launchTranGeneral(eng->gpTran, d_params, B, tstep, step_first, n_steps, dProbe, np, os, d_wave, d_x,
                                            reinterpret_cast<long long*>(d_iters), d_status, d_step_iters, nullptr, hs,
-                                           nullptr, -1, dDone, maxSteps, dDone ? eng->dKnownAlts : nullptr,
-                                           dDone ? eng->nKnownAlts : 0));
+                                           nullptr, -1, dDone, maxSteps, handBack ? eng->dKnownAlts : nullptr,
+                                           handBack ? eng->nKnownAlts : 0));
         }
         return CSIM_OK;
     };
@@ -344,10 +345,10 @@ int csim_tran_batch_dev(csim_engine* eng, const double* d_params, int32_t B, dou
     if (rc) return rc;
     // one round per violation episode; the general kernel keeps an instance until a whole step ran on
     // recorded sequences again (small kernels) or for at most handBackAfter steps
-    static const int rounds = std::getenv("CSIM_HYBRID_ROUNDS") ? std::atoi(std::getenv("CSIM_HYBRID_ROUNDS")) : 8;
-    static const int handBackAfter = std::getenv("CSIM_HYBRID_STEPS") ? std::atoi(std::getenv("CSIM_HYBRID_STEPS")) : 64;
+    const int rounds = std::getenv("CSIM_HYBRID_ROUNDS") ? std::atoi(std::getenv("CSIM_HYBRID_ROUNDS")) : 4;
+    const int handBackAfter = std::getenv("CSIM_HYBRID_STEPS") ? std::atoi(std::getenv("CSIM_HYBRID_STEPS")) : 64;
     for (int r = 0; r < rounds; ++r) {
-        if ((rc = general(eng->dDone, handBackAfter))) return rc;
+        if ((rc = general(eng->dDone, handBackAfter, true))) return rc;
         if ((rc = scheduled())) return rc;
     }
     return general(eng->dDone, 2147483647);      // whatever is still unfinished runs to the end of the launch

@@ -242,11 +242,14 @@ def test_hybrid_stepping_when_no_alternative_fits(torch_mod, tmp_path, monkeypat
     slow = _run_tran(torch_mod, eng, params, 300, nl.tstep, want_step_iters=True)
     eng.jit_scheduled(params, plan_steps=3)                          # 3 quiet steps: one sequence only
     assert eng.tran_kernel == "scheduled"
-    fast = _run_tran(torch_mod, eng, params, 300, nl.tstep, want_step_iters=True)
-    assert ((fast["status"] & FALLBACK) != 0).any()                  # the hand-over really happened
-    assert np.array_equal(fast["step_iters"], slow["step_iters"])
-    assert np.array_equal(fast["status"] & NOFB, slow["status"])
-    assert rel_err(fast["x"].T, slow["x"].T, nl.n_node_eq).max() < TOL
+    for rounds in ("4", "1", "0"):          # 0 rounds: straight from the first violation to the final launch
+        monkeypatch.setenv("CSIM_HYBRID_ROUNDS", rounds)
+        fast = _run_tran(torch_mod, eng, params, 300, nl.tstep, want_step_iters=True)
+        assert ((fast["status"] & FALLBACK) != 0).any(), rounds      # the hand-over really happened
+        assert np.array_equal(fast["step_iters"], slow["step_iters"]), rounds
+        assert np.array_equal(fast["iters"], slow["iters"]), rounds
+        assert np.array_equal(fast["status"] & NOFB, slow["status"]), rounds
+        assert rel_err(fast["x"].T, slow["x"].T, nl.n_node_eq).max() < TOL, rounds
 
 
 def test_scheduled_kernel_ragged_batch(engines, torch_mod):
