@@ -25,6 +25,7 @@ def main():
     os.makedirs(dst, exist_ok=True)
     bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
     cmd = open(os.path.join(src, "command.txt")).read().strip()
+    n_steps = bench["steps"] + bench["warmup"]
 
     # kernel-trace stats (only this repo's kernels + the total)
     stats = list(csv.DictReader(open(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0])))
@@ -51,8 +52,12 @@ def main():
             acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
             meta[k] = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["Scratch_Size"], r["VGPR_Count"],
                        r["Accum_VGPR_Count"], r["SGPR_Count"])
+        # one bench step = one call of csim_tran_batch_dev = several launches (the scheduled kernel, then
+        # hand-back rounds that are idle unless an instance left its recorded schedules): report the
+        # SUM over a step's launches, i.e. total / number of bench steps, not a per-dispatch mean
         for (k, c), v in acc.items():
-            pmc[k][c] = sum(v) / len(v)
+            per = n_steps if "tran" in k else 1
+            pmc[k][c] = sum(v) / max(per, 1)
     counters = sorted({c for k in pmc for c in pmc[k]})
     with open(os.path.join(dst, tag + "_pmc.csv"), "w") as f:
         w = csv.writer(f)
@@ -87,9 +92,12 @@ def main():
     for r in ours:
         lines.append("| %s | %s | %.3f | %s %% |" % (r["Name"].split("(")[0], r["Calls"], float(r["AverageNs"]) / 1e6,
                                                     r["Percentage"]))
-    lines += ["", "rocprofv3 average of `%s`: %.3f ms; bench.py's HIP-event average of the same launches: %.3f ms."
-              % (dname, float(dom["AverageNs"]) / 1e6, bench["roofline"]["kernel_avg_ms"]), "",
-              "## PMC (separate `--pmc` passes, mean per dispatch)", ""]
+    tran_total_ms = sum(float(r["TotalDurationNs"]) for r in ours if "tran" in r["Name"]) / 1e6
+    lines += ["", "One bench step = one `csim_tran_batch_dev` call = the scheduled launch plus hand-back rounds (idle "
+              "here). rocprofv3: all transient launches of a step sum to %.3f ms (%.3f ms of it `%s`); bench.py's "
+              "HIP-event time of the same step: %.3f ms." % (tran_total_ms / n_steps, float(dom["TotalDurationNs"]) / 1e6 / n_steps,
+                                                            dname, bench["roofline"]["kernel_avg_ms"]), "",
+              "## PMC (separate `--pmc` passes; transient kernels: sum over the launches of one bench step)", ""]
     for k in sorted(pmc):
         lines.append("**%s** grid=%s wg=%s LDS=%s B scratch=%s B VGPR=%s AGPR=%s" % ((k,) + meta[k][:6]))
         for c in counters:
