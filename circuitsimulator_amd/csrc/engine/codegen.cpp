@@ -105,7 +105,7 @@ uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch)
         for (std::size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
     };
     auto mixInt = [&](int32_t v) { mixBytes(&v, sizeof v); };
-    mixInt(9);                                            // generator revision
+    mixInt(10);                                           // generator revision
     mixInt(ir.n_unknowns); mixInt(ir.n_node_eq); mixInt(ir.n_branch_eq);
     mixInt(ir.n_elems); mixInt(ir.n_params); mixInt(ir.has_nonlinear);
     for (int e = 0; e < ir.n_elems; ++e) {
@@ -266,6 +266,7 @@ struct VariantOptions {
     bool rich;          // launch constants and loop parameters in LDS
     bool stepInLds;     // per-step terms (sources, history currents) in LDS (else registers)
     int parkBudget;     // how many finished U-row values may be parked in LDS (-1 = all)
+    int ckUnroll = 4;   // unroll factor of the per-step checkpoint loop (swept 1/2/4/8/31: 4 best, 31 pins 2N VGPRs)
 };
 
 // emits ONE __global__ kernel; returns the number of LDS doubles per lane it uses
@@ -439,7 +440,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         << "        if (live) {     // checkpoint: state at the start of this step.  A ROLLED loop: unrolled,\n"
         << "                        // hipcc hoists the N store addresses out of the time loop and pins 2N VGPRs\n"
         << "            double* ck = xio + b;\n"
-        << "#pragma unroll 1\n"
+        << "#pragma unroll " << opt.ckUnroll << "\n"
         << "            for (int i = 0; i < " << N << "; ++i, ck += SB) *ck = X(i);\n"
         << "        }\n";
 
@@ -784,6 +785,7 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "    r = fma(fma(-a, r, 1.0), r, r);\n"
         << "    return r;\n}\n\n";
 
+    const int leanBudget = 80 - N;
     // a variant is emitted only if its LDS image fits one CU (163 840 B)
     auto emitVariant = [&](const VariantOptions& opt, CodegenStats* st) {
         std::ostringstream k;
@@ -798,7 +800,6 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     };
     // lean: 40 KB of LDS per wave (4 waves per CU): x, then finished U rows up to the budget;
     // for N > 80 the iterate alone exceeds that and the kernel runs fewer waves per CU
-    const int leanBudget = 80 - N;
     const int ldsLean = emitVariant({"csim_tran_sched_kernel", false, false, leanBudget > 0 ? leanBudget : 0}, statsOut);
     if (ldsLean < 0) return std::string();          // the iterate does not fit LDS: no scheduled kernel
     // rich: same residency, every finished U row parked (more LDS per wave: fewer waves per CU)
@@ -812,7 +813,9 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         for (std::size_t k = 0; k < sweep.size(); ++k) {
             static std::vector<std::string> names;
             names.push_back("csim_tran_sched_kernel_sweep" + std::to_string(k));
-            emitVariant({names.back().c_str(), false, false, sweep[k]}, nullptr);
+            // value >= 1000: checkpoint-unroll sweep (value - 1000) at the lean park budget
+            if (sweep[k] >= 1000) emitVariant({names.back().c_str(), false, false, leanBudget > 0 ? leanBudget : 0, sweep[k] - 1000}, nullptr);
+            else emitVariant({names.back().c_str(), false, false, sweep[k]}, nullptr);
         }
     }
 
