@@ -676,3 +676,46 @@ def test_cpp_batch_api(engines):
         assert r["rows"] == 2                                   # out_stride = n_steps: t = 0 and the last row
         assert rel_err(np.array(r["x_final"]), o["x_final"], nl.n_node_eq).max() < TOL
         assert abs(r["wave_last"] - o["x_final"][-1]) <= TOL * max(abs(o["x_final"][-1]), 1e-6)
+
+
+@pytest.mark.parametrize("variant", ["r_zero", "c_nonpositive", "l_zero"])
+def test_degenerate_element_values_follow_the_reference(variant, torch_mod, tmp_path, monkeypatch):
+    """a zero-ohm resistor is skipped (element.cpp:20-23); C <= 0 and L <= 0
+    contribute nothing in transient (tanalisis.cpp:65,296) -- an L <= 0 inductor leaves its branch row
+    empty, the factorisation fails and every solve returns the ZERO vector (solver.hpp:94-97), which
+    the damped update then relaxes towards.  General kernel, JIT kernel (whose +-1 folding of the
+    inductor incidence is guarded by an L > 0 precondition) and oracle must agree."""
+    import shutil, os
+    from circuitsimulator_amd import Engine, Netlist
+    monkeypatch.setenv("CSIM_JIT_DIR", str(tmp_path / "jit"))
+    base = ["VDD vdd 0 DC 2", "Vin in 0 SIN 1 0.5 200e6 0", "Rg in g 50", "M1 d g 0 n 20e-6 0.5e-6 2", "Rd vdd d 500",
+            "R2 d o 30", "L1 o p 1e-9", "C1 p 0 0.3e-12", "R3 p 0 2e3",
+            ".MODEL 2 VT 0.55 MU 6e-2 COX 2e-3 LAMBDA 0.04 CJ0 2e-14", ".TRAN 5e-12 1e-9"]
+    edit = {"r_zero": ("R2 d o 30", "R2 d o 0\nR2b d o 30"), "c_nonpositive": ("C1 p 0 0.3e-12", "C1 p 0 -1e-12"),
+            "l_zero": ("L1 o p 1e-9", "L1 o p 0")}[variant]
+    nl = Netlist.from_text("\n".join(base).replace(edit[0], edit[1]) + "\n")
+    eng = Engine(nl, 0)
+    B, steps = 6, 120
+    params = eng.mc_params(3, 0.05, 0, B)
+    gen = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+    ph = params.cpu().numpy()
+    for b in (0, B - 1):
+        xo, ito, sto = _orc().dc(nl.ir_ptr, nl.n_unknowns, ph, b)
+        assert gen["dc_iters"][b] == ito
+        assert rel_err(gen["x_dc"][:, b], xo, nl.n_node_eq).max() < TOL
+        o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstep * steps, x0=xo, want_rows=False, want_step_iters=True)
+        assert gen["iters"][b] == o["iters"] and np.array_equal(gen["step_iters"][:, b], o["step_iters"])
+        assert gen["status"][b] == (o["status"] | sto)
+        assert rel_err(gen["x"][:, b], o["x_final"], nl.n_node_eq).max() < TOL
+    if variant == "l_zero":
+        assert (gen["status"] & 0x4).all()                       # CSIM_ST_LU_TINY_PIVOT on every instance
+    if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+        try:
+            eng.jit_scheduled(params, plan_steps=20)
+        except Exception:
+            assert variant == "l_zero"                           # no successful factorisation to plan from
+            return
+        fast = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+        assert np.array_equal(fast["step_iters"], gen["step_iters"])
+        assert np.array_equal(fast["status"] & NOFB, gen["status"])
+        assert rel_err(fast["x"].T, gen["x"].T, nl.n_node_eq).max() < TOL
