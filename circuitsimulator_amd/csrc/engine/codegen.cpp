@@ -580,6 +580,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         // ---- elimination with the scheduled pivots (solver.hpp:46-77), RHS carried along
         std::vector<AV> rinv(static_cast<std::size_t>(N));      // 1 / U(k,k)
         int parked = 0;
+        const bool groupChecks = std::getenv("CSIM_CG_GROUP") != nullptr;
         const int splitEvery = std::getenv("CSIM_CG_SPLIT") ? std::max(1, std::atoi(std::getenv("CSIM_CG_SPLIT"))) : 0;
         for (int k = 0; k < N; ++k) {
             const int p = sc.pivotPos[static_cast<std::size_t>(k)];
@@ -602,12 +603,10 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
                 g.out << g.ind << pvName << " = true;   // scheduled pivot is a structural zero\n";
             } else {
                 const std::string absP = ap_.kind == AV::CONST ? lit(std::fabs(ap_.c)) : "fabs(" + ap_.v + ")";
-                if (ap_.kind == AV::DYN) {
-                    g.out << g.ind << pvName << " = " << pvName << " || !(" << absP << " >= " << lit(K.lu_eps) << ");\n";
-                    ++g.st.nCmp;
-                } else if (std::fabs(ap_.c) < K.lu_eps) {
-                    g.out << g.ind << pvName << " = true;\n";
-                }
+                std::vector<std::string> conds;        // all must hold
+                bool contradiction = false;
+                if (ap_.kind == AV::DYN) { conds.push_back("(" + absP + " >= " + lit(K.lu_eps) + ")"); ++g.st.nCmp; }
+                else if (std::fabs(ap_.c) < K.lu_eps) contradiction = true;
                 for (int i = k; i < N; ++i) {
                     if (i == p) continue;
                     const AV& ai = at(i, k);
@@ -615,12 +614,21 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
                     const bool before = i < p;
                     if (ai.kind == AV::CONST && ap_.kind == AV::CONST) {
                         const bool ok = before ? (std::fabs(ap_.c) > std::fabs(ai.c)) : (std::fabs(ap_.c) >= std::fabs(ai.c));
-                        if (!ok) g.out << g.ind << pvName << " = true;   // schedule contradicts constant entries\n";
+                        if (!ok) contradiction = true;   // schedule contradicts constant entries
                         continue;
                     }
                     const std::string absI = ai.kind == AV::CONST ? lit(std::fabs(ai.c)) : "fabs(" + ai.v + ")";
-                    g.out << g.ind << pvName << " = " << pvName << " || !(" << absP << (before ? " > " : " >= ") << absI << ");\n";
+                    conds.push_back("(" + absP + (before ? " > " : " >= ") + absI + ")");
                     ++g.st.nCmp;
+                }
+                if (contradiction) g.out << g.ind << pvName << " = true;\n";
+                else if (groupChecks && !conds.empty()) {
+                    // one test (and one block boundary) per column: comparisons combined without short-circuit
+                    std::string e;
+                    for (std::size_t c = 0; c < conds.size(); ++c) e += (c ? " & " : "") + conds[c];
+                    g.out << g.ind << pvName << " = " << pvName << " || !(" << e << ");\n";
+                } else {
+                    for (const std::string& c : conds) g.out << g.ind << pvName << " = " << pvName << " || !" << c << ";\n";
                 }
             }
             if (p != k) {
