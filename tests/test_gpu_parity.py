@@ -719,3 +719,20 @@ def test_degenerate_element_values_follow_the_reference(variant, torch_mod, tmp_
         assert np.array_equal(fast["step_iters"], gen["step_iters"])
         assert np.array_equal(fast["status"] & NOFB, gen["status"])
         assert rel_err(fast["x"].T, gen["x"].T, nl.n_node_eq).max() < TOL
+
+
+def test_batch4096_every_instance_against_the_oracle(engines, torch_mod):
+    """configs[2] size: all 4096 Monte-Carlo instances (not a sample) against the CPU oracle on the
+    same parameter table -- NR counts per instance equal, every unknown within the parity bar."""
+    nl, eng = engines["dbmixer"]
+    B, steps = 4096, 30
+    params = eng.mc_params(12345, 0.05, 0, B)
+    r = _run_tran(torch_mod, eng, params, steps, nl.tstep)
+    assert not (r["status"] & 0x27).any()
+    ph = params.cpu().numpy()
+    worst = 0.0
+    for b in range(B):
+        o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstep * steps, want_rows=False)
+        assert r["iters"][b] == o["iters"], b
+        worst = max(worst, rel_err(r["x"][:, b], o["x_final"], nl.n_node_eq).max())
+    assert worst < TOL, worst
