@@ -132,14 +132,23 @@ int eqOf(const Circuit& ckt, int nodeId) { return ckt.nodes[static_cast<std::siz
 
 void fillSource(csim::IrRecord& r, const SourceSpec& s)
 {
-    r.nParams = CSIM_PARAMS_SRC;
-    r.params[0] = s.dcValue;
-    r.params[1] = s.tran.sine.v0;
-    r.params[2] = s.tran.sine.va;
-    r.params[3] = s.tran.sine.freq;
-    r.params[4] = s.tran.sine.td;
-    r.params[5] = s.tran.sine.phi;
-    r.wave = (s.tran.type == WaveformType::SIN) ? CSIM_WAVE_SIN : CSIM_WAVE_NONE;
+    r.params.assign(1, s.dcValue);
+    if (s.tran.type == WaveformType::PULSE) {
+        const PulseSpec& p = s.tran.pulse;
+        r.wave = CSIM_WAVE_PULSE;
+        for (double v : {p.v1, p.v2, p.td, p.tr, p.tf, p.ton, p.per}) r.params.push_back(v);
+    } else if (s.tran.type == WaveformType::PWL) {
+        const PwlSpec& w = s.tran.pwl;
+        const std::size_t n = w.t.size() < w.v.size() ? w.t.size() : w.v.size();
+        r.wave = CSIM_WAVE_PWL;
+        r.waveN = static_cast<int>(n);
+        for (std::size_t i = 0; i < n; ++i) r.params.push_back(w.t[i]);
+        for (std::size_t i = 0; i < n; ++i) r.params.push_back(w.v[i]);
+    } else {
+        r.wave = (s.tran.type == WaveformType::SIN) ? CSIM_WAVE_SIN : CSIM_WAVE_NONE;
+        for (double v : {s.tran.sine.v0, s.tran.sine.va, s.tran.sine.freq, s.tran.sine.td, s.tran.sine.phi}) r.params.push_back(v);
+    }
+    r.nParams = static_cast<int>(r.params.size());
 }
 } // namespace
 
@@ -150,7 +159,7 @@ csim::IrRecord Resistor::describe(const Circuit& ckt) const
     r.eq[0] = eqOf(ckt, nodeIds[0]);
     r.eq[1] = eqOf(ckt, nodeIds[1]);
     r.nParams = CSIM_PARAMS_R;
-    r.params[0] = R;
+    r.params = {R};
     return r;
 }
 
@@ -161,7 +170,7 @@ csim::IrRecord CapacitorElement::describe(const Circuit& ckt) const
     r.eq[0] = eqOf(ckt, nodeIds[0]);
     r.eq[1] = eqOf(ckt, nodeIds[1]);
     r.nParams = CSIM_PARAMS_C;
-    r.params[0] = C;
+    r.params = {C};
     return r;
 }
 
@@ -173,7 +182,7 @@ csim::IrRecord Inductor::describe(const Circuit& ckt) const
     r.eq[1] = eqOf(ckt, nodeIds[1]);
     r.branchEq = branchEqIndex;
     r.nParams = CSIM_PARAMS_L;
-    r.params[0] = L;
+    r.params = {L};
     return r;
 }
 
@@ -204,10 +213,7 @@ csim::IrRecord MosfetBase::describe(const Circuit& ckt) const
     r.kind = isP ? CSIM_PMOS : CSIM_NMOS;
     for (int t = 0; t < 4; ++t) r.eq[t] = eqOf(ckt, nodeIds[static_cast<std::size_t>(t)]);
     r.nParams = CSIM_PARAMS_MOS;
-    r.params[0] = Vth;
-    r.params[1] = K;
-    r.params[2] = lambda;
-    r.params[3] = Cj0;
+    r.params = {Vth, K, lambda, Cj0};
     r.mosMu = mu_; r.mosCox = cox_; r.mosW = w_; r.mosL = l_;
     return r;
 }
@@ -234,13 +240,14 @@ CircuitIR flatten(const Circuit& ckt)
         for (int t = 0; t < 4; ++t) out.eq.push_back(r.eq[t]);
         out.branchEq.push_back(r.branchEq);
         out.wave.push_back(r.wave);
+        out.waveN.push_back(r.waveN);
         out.paramSlot.push_back(static_cast<int32_t>(out.nominal.size()));
         if (r.branchEq >= 0 && r.branchEq < nNode + nBranch)
             out.eqNames[static_cast<std::size_t>(r.branchEq)] = e->getName();
         const bool mos = (r.kind == CSIM_NMOS || r.kind == CSIM_PMOS);
         nonlinear = nonlinear || mos;
         for (int p = 0; p < r.nParams; ++p) {
-            out.nominal.push_back(r.params[p]);
+            out.nominal.push_back(r.params[static_cast<std::size_t>(p)]);
             int mc = 0;
             if (r.kind == CSIM_R || r.kind == CSIM_C || r.kind == CSIM_L) mc = 1;
             else if (mos && p == 0) mc = 1;    // VT

@@ -73,7 +73,7 @@ namespace csim {
 
 // owning storage behind a csim_ir view
 struct CircuitIR {
-    std::vector<int32_t> kind, eq, branchEq, paramSlot, wave;
+    std::vector<int32_t> kind, eq, branchEq, paramSlot, wave, waveN;
     std::vector<double> nominal;          // P nominal parameter values
     // Monte-Carlo recipe per parameter slot (see engine/mc.hip):
     //   mcKind[p]: 0 fixed, 1 scale by (1+sigma z), 2 MOS K rebuilt from MU draw
@@ -93,6 +93,7 @@ struct CircuitIR {
         ir.branch_eq = branchEq.data();
         ir.param_slot = paramSlot.data();
         ir.wave = wave.data();
+        ir.wave_n = waveN.data();
         return &ir;
     }
 };

@@ -27,8 +27,9 @@ struct IrRecord {
     int eq[4] = {-1, -1, -1, -1};   // terminal equation indices (-1 = ground)
     int branchEq = -1;
     int wave = CSIM_WAVE_NONE;
+    int waveN = 0;                  // PWL: number of points
     int nParams = 0;
-    double params[CSIM_PARAMS_SRC] = {0, 0, 0, 0, 0, 0};
+    std::vector<double> params;     // nParams values
     // how a Monte-Carlo draw perturbs this element (engine/mc.hip):
     //   scaleMask bit i: params[i] *= (1 + sigma z)
     //   MOS: Vth scaled directly; K rebuilt as (MU(1+sigma z))*COX*(W/L)

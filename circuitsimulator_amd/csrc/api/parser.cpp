@@ -171,6 +171,66 @@ void NetlistParser::twoTerminal(const Statement& st, char kind)
     else                  ckt.addInductor(t[0], t[1], t[2], value);
 }
 
+// PULSE / PWL waveforms.  The reference's netlist dialect has no syntax for them (its parser
+// rejects the statement, src/parser.cpp:330-345) although its solver evaluates them
+// (include/sim.hpp:80-138) for circuits built through the C++ API.  Accepted here as a superset:
+//   PULSE v1 v2 [td [tr [tf [ton [per]]]]]      PWL t0 v0 t1 v1 ...
+// with optional SPICE-style parentheses and commas.  Returns true when a waveform keyword was
+// consumed (valid or not).
+namespace {
+bool startsWithKeyword(const std::string& token, const char* kw)
+{
+    const std::string low = toLower(token);
+    const std::string k(kw);
+    return low.compare(0, k.size(), k) == 0 && (low.size() == k.size() || low[k.size()] == '(');
+}
+
+bool parsePulseOrPwl(const std::vector<std::string>& t, std::size_t next, int lineNo, const std::string& raw,
+                     SourceSpec& spec)
+{
+    if (next >= t.size()) return false;
+    const bool pulse = startsWithKeyword(t[next], "pulse");
+    const bool pwl = startsWithKeyword(t[next], "pwl");
+    if (!pulse && !pwl) return false;
+
+    std::string rest;
+    for (std::size_t i = next; i < t.size(); ++i) rest += t[i] + " ";
+    rest = rest.substr(pulse ? 5 : 3);
+    for (char& c : rest) if (c == '(' || c == ')' || c == ',') c = ' ';
+    std::vector<double> vals;
+    try {
+        std::istringstream is(rest);
+        std::string tok;
+        while (is >> tok) vals.push_back(parseSpiceNumber(tok));
+    } catch (const std::exception& e) {
+        std::cerr << "Line " << lineNo << ": cannot parse " << (pulse ? "PULSE" : "PWL") << " parameters: "
+                  << e.what() << " in '" << raw << "'\n";
+        return true;
+    }
+    if (pulse) {
+        if (vals.size() < 2 || vals.size() > 7) {
+            std::cerr << "Line " << lineNo << ": PULSE needs 2 to 7 parameters (v1 v2 td tr tf ton per): " << raw << "\n";
+            return true;
+        }
+        vals.resize(7, 0.0);
+        PulseSpec p;
+        p.v1 = vals[0]; p.v2 = vals[1]; p.td = vals[2]; p.tr = vals[3]; p.tf = vals[4]; p.ton = vals[5]; p.per = vals[6];
+        spec.tran.type = WaveformType::PULSE;
+        spec.tran.pulse = p;
+    } else {
+        if (vals.size() < 2 || vals.size() % 2 != 0) {
+            std::cerr << "Line " << lineNo << ": PWL needs (time value) pairs: " << raw << "\n";
+            return true;
+        }
+        PwlSpec w;
+        for (std::size_t i = 0; i < vals.size(); i += 2) { w.t.push_back(vals[i]); w.v.push_back(vals[i + 1]); }
+        spec.tran.type = WaveformType::PWL;
+        spec.tran.pwl = w;
+    }
+    return true;
+}
+} // namespace
+
 // Vname np nm <value> [SIN ...] | Vname np nm DC <value> [SIN ...] |
 // Vname np nm SIN v0 va freq [td [phi]]
 void NetlistParser::voltageSource(const Statement& st)
@@ -187,7 +247,7 @@ void NetlistParser::voltageSource(const Statement& st)
         if (t.size() >= 5 && toLower(t[3]) == "dc") {
             spec.dcValue = parseSpiceNumber(t[4]);
             next = 5;
-        } else if (toLower(t[3]) == "sin") {
+        } else if (toLower(t[3]) == "sin" || startsWithKeyword(t[3], "pulse") || startsWithKeyword(t[3], "pwl")) {
             spec.dcValue = 0.0;
             next = 3;
         } else {
@@ -200,7 +260,9 @@ void NetlistParser::voltageSource(const Statement& st)
         return;
     }
 
-    if (next < t.size() && toLower(t[next]) == "sin") {
+    if (parsePulseOrPwl(t, next, st.lineNo, st.raw, spec)) {
+        // superset of the reference dialect, see above
+    } else if (next < t.size() && toLower(t[next]) == "sin") {
         // SIN v0 va freq [td [phi]] -- td in seconds, phi in radians
         if (t.size() < next + 4) {
             std::cerr << "Line " << st.lineNo << ": SIN needs at least 3 parameters (v0 va freq): "
@@ -224,7 +286,7 @@ void NetlistParser::voltageSource(const Statement& st)
     ckt.addVoltageSource(t[0], t[1], t[2], spec);
 }
 
-// Iname np nm [DC] value
+// Iname np nm [DC] value        (+ optional PULSE / PWL waveform: superset, see above)
 void NetlistParser::currentSource(const Statement& st)
 {
     const auto& t = st.tokens;
@@ -235,7 +297,12 @@ void NetlistParser::currentSource(const Statement& st)
     SourceSpec spec;
     try {
         const bool dcForm = t.size() >= 5 && toLower(t[3]) == "dc";
-        spec.dcValue = parseSpiceNumber(dcForm ? t[4] : t[3]);
+        if (startsWithKeyword(t[3], "pulse") || startsWithKeyword(t[3], "pwl")) {
+            parsePulseOrPwl(t, 3, st.lineNo, st.raw, spec);
+        } else {
+            spec.dcValue = parseSpiceNumber(dcForm ? t[4] : t[3]);
+            parsePulseOrPwl(t, dcForm ? 5 : 4, st.lineNo, st.raw, spec);
+        }
     } catch (const std::exception& e) {
         std::cerr << "Line " << st.lineNo << ": cannot parse I value: " << e.what()
                   << " in '" << st.raw << "'\n";

@@ -348,7 +348,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             case CSIM_C: toLdsTerm(tb + T_C_GC); break;
             case CSIM_L: toLdsTerm(tb + T_L_REQ); break;
             case CSIM_V: case CSIM_I:
-                for (int o = 0; o < 6; ++o) {
+                for (int o = 0, cnt = (e + 1 < ir.n_elems ? ir.param_slot[e + 1] : ir.n_params) - sl; o < cnt; ++o) {
                     toLdsParam(sl + o);
                     // lean: source parameters are needed once per time step only -- re-read them
                     // from the table (L2-resident) instead of pinning 6 doubles per source in
@@ -459,6 +459,49 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
                         << i2 << "else " << sname(tb) << " = " << pRef[static_cast<std::size_t>(s)] << " + (" << pRef[static_cast<std::size_t>(s + 1)] << " + " << pRef[static_cast<std::size_t>(s + 2)]
                         << " * sin((2.0 * " << lit(K.pi) << " * " << pRef[static_cast<std::size_t>(s + 3)] << ") * (tNow - " << pRef[static_cast<std::size_t>(s + 4)] << ") + "
                         << pRef[static_cast<std::size_t>(s + 5)] << "));\n";
+                } else if (ir.wave[e] == CSIM_WAVE_PULSE) {
+                    // TranWaveform::eval PULSE (reference include/sim.hpp:80-115)
+                    auto P = [&](int o) { return pRef[static_cast<std::size_t>(s + o)]; };
+                    src << i2 << "{\n"
+                        << i2 << "    const double v1 = " << P(1) << ", v2 = " << P(2) << ", td = " << P(3) << ", tr = " << P(4)
+                        << ", tf = " << P(5) << ", ton = " << P(6) << ", per = " << P(7) << ";\n"
+                        << i2 << "    double w;\n"
+                        << i2 << "    if (per <= 0.0) {\n"
+                        << i2 << "        const double tau = tNow - td;\n"
+                        << i2 << "        if (tau <= 0.0) w = v1;\n"
+                        << i2 << "        else if (tau < tr) w = v1 + clamp01_cg(tau / tr) * (v2 - v1);\n"
+                        << i2 << "        else if (tau < tr + ton) w = v2;\n"
+                        << i2 << "        else w = v2 + clamp01_cg((tau - (tr + ton)) / tf) * (v1 - v2);\n"
+                        << i2 << "    } else if (tNow < td) {\n"
+                        << i2 << "        w = v1;\n"
+                        << i2 << "    } else {\n"
+                        << i2 << "        double tau = fmod(tNow - td, per);\n"
+                        << i2 << "        if (tau < 0.0) tau += per;\n"
+                        << i2 << "        if (tau < tr) w = v1 + (v2 - v1) * clamp01_cg(tau / tr);\n"
+                        << i2 << "        else if (tau < tr + ton) w = v2;\n"
+                        << i2 << "        else if (tau < tr + ton + tf) w = v2 + (v1 - v2) * clamp01_cg((tau - (tr + ton)) / tf);\n"
+                        << i2 << "        else w = v1;\n"
+                        << i2 << "    }\n"
+                        << i2 << "    " << sname(tb) << " = " << P(0) << " + w;\n"
+                        << i2 << "}\n";
+                } else if (ir.wave[e] == CSIM_WAVE_PWL) {
+                    // TranWaveform::eval PWL (reference include/sim.hpp:124-138), unrolled over the points
+                    const int n = ir.wave_n[e];
+                    auto PT = [&](int i) { return pRef[static_cast<std::size_t>(s + 1 + i)]; };
+                    auto PV = [&](int i) { return pRef[static_cast<std::size_t>(s + 1 + n + i)]; };
+                    src << i2 << "{\n" << i2 << "    double w;\n";
+                    if (n <= 0) {
+                        src << i2 << "    w = 0.0;\n";
+                    } else {
+                        src << i2 << "    if (tNow <= " << PT(0) << ") w = " << PV(0) << ";\n"
+                            << i2 << "    else if (tNow >= " << PT(n - 1) << ") w = " << PV(n - 1) << ";\n";
+                        for (int i = 0; i + 1 < n; ++i)
+                            src << i2 << "    else if (tNow > " << PT(i) << " && tNow <= " << PT(i + 1) << ") { const double ta = " << PT(i)
+                                << ", tb = " << PT(i + 1) << ", va = " << PV(i) << ", vb = " << PV(i + 1)
+                                << "; w = va + (vb - va) * ((tNow - ta) / (tb - ta)); }\n";
+                        src << i2 << "    else w = " << PV(n - 1) << ";\n";
+                    }
+                    src << i2 << "    " << sname(tb) << " = " << pRef[static_cast<std::size_t>(s)] << " + w;\n" << i2 << "}\n";
                 } else {
                     src << i2 << sname(tb) << " = " << pRef[static_cast<std::size_t>(s)] << " + 0.0;\n";
                 }
@@ -787,6 +830,7 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "#define ST_TRAN_NONFINITE 0x0001u\n#define ST_TRAN_NONCONV 0x0002u\n\n"
         << "#define Q(k) lds[(k) * 64 + lane]\n#define X(i) Q(i)\n#define S(j) Q(" << N << " + (j))\n\n"
         << "// Newton-refined reciprocal (v_rcp_f64 + 2 FMA pairs, ~1 ulp) for the pivots\n"
+        << "__device__ __forceinline__ double clamp01_cg(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }\n"
         << "__device__ __forceinline__ double rcp_nr(double a)\n{\n"
         << "    double r = __builtin_amdgcn_rcp(a);\n"
         << "    r = fma(fma(-a, r, 1.0), r, r);\n"

@@ -27,7 +27,7 @@ namespace csim {
 struct GenPlan {
     int N, LD, nNodeEq, nElem, P, nTerms, termOne, termGmin;
     int nnzG, nnzI, hasNonlinear, pad;
-    const int32_t *kind, *eq, *branch, *slot, *wave, *termBase;
+    const int32_t *kind, *eq, *branch, *slot, *wave, *waveN, *termBase;
     const int32_t *gPtr, *gPos, *gCon;
     const int32_t *iPtr, *iRow, *iCon;
     csim_consts k;
@@ -91,22 +91,66 @@ __device__ __forceinline__ double source_value_dc(const double* Pv, int slot, in
     return base * scale;
 }
 
-// SourceSpec::evalTran (sim.hpp:160-162) with TranWaveform::eval SIN (:117-122)
-__device__ __forceinline__ double source_value_tran(const double* Pv, int slot, int wave, double t, double pi)
+__device__ __forceinline__ double clamp01_dev(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
+
+// SourceSpec::evalTran (sim.hpp:160-162) with TranWaveform::eval (:75-143): SIN, PULSE, PWL.
+// PS = stride between consecutive parameter slots (1 for an LDS copy, B for the global table).
+template <typename PGet>
+__device__ __forceinline__ double source_wave_value(PGet P, int wave, int waveN, double t, double pi)
 {
-    const double dc = Pv[slot + 0];
     double w = 0.0;
     if (wave == CSIM_WAVE_SIN) {
-        const double v0 = Pv[slot + 1], va = Pv[slot + 2], freq = Pv[slot + 3];
-        const double td = Pv[slot + 4], phi = Pv[slot + 5];
+        const double v0 = P(1), va = P(2), freq = P(3);
+        const double td = P(4), phi = P(5);
         if (t < td) w = v0;
         else {
             const double tau = t - td;
             const double om = 2.0 * pi * freq;
             w = v0 + va * sin(om * tau + phi);
         }
+    } else if (wave == CSIM_WAVE_PULSE) {
+        const double v1 = P(1), v2 = P(2), td = P(3), tr = P(4), tf = P(5), ton = P(6), per = P(7);
+        if (per <= 0.0) {
+            const double tau = t - td;
+            if (tau <= 0.0) w = v1;
+            else if (tau < tr) { const double k = clamp01_dev(tau / tr); w = v1 + k * (v2 - v1); }
+            else if (tau < tr + ton) w = v2;
+            else { const double tfall = tau - (tr + ton); const double k = clamp01_dev(tfall / tf); w = v2 + k * (v1 - v2); }
+        } else if (t < td) {
+            w = v1;
+        } else {
+            double tau = fmod(t - td, per);
+            if (tau < 0.0) tau += per;
+            if (tau < tr) { const double k = clamp01_dev(tau / tr); w = v1 + (v2 - v1) * k; }
+            else if (tau < tr + ton) w = v2;
+            else if (tau < tr + ton + tf) { const double tfall = tau - (tr + ton); const double k = clamp01_dev(tfall / tf); w = v2 + (v1 - v2) * k; }
+            else w = v1;
+        }
+    } else if (wave == CSIM_WAVE_PWL) {
+        const int n = waveN;
+        if (n <= 0) w = 0.0;
+        else if (t <= P(1)) w = P(1 + n);
+        else if (t >= P(n)) w = P(2 * n);
+        else {
+            w = P(2 * n);
+            for (int i = 0; i + 1 < n; ++i) {
+                const double ta = P(1 + i), tb = P(2 + i);
+                if (t > ta && t <= tb) {
+                    const double va = P(1 + n + i), vb = P(2 + n + i);
+                    const double k = (t - ta) / (tb - ta);
+                    w = va + (vb - va) * k;
+                    break;
+                }
+            }
+        }
     }
-    return dc + w;
+    return w;
+}
+
+__device__ __forceinline__ double source_value_tran(const double* Pv, int slot, int wave, int waveN, double t, double pi)
+{
+    const double dc = Pv[slot + 0];
+    return dc + source_wave_value([&](int i) { return Pv[slot + i]; }, wave, waveN, t, pi);
 }
 
 // Level-1 MOSFET linearisation at (Vd, Vg, Vs): MosfetBase::stamp, element.cpp:207-274
@@ -178,7 +222,7 @@ __device__ __forceinline__ void terms_step_tran(const GenPlan& pl, const double*
         const int kind = pl.kind[e], s = pl.slot[e], tb = pl.termBase[e];
         const int32_t* q = pl.eq + 4 * e;
         if (kind == CSIM_V || kind == CSIM_I) {
-            T[tb + T_SRC_VAL] = source_value_tran(Pv, s, pl.wave[e], t, pl.k.pi);
+            T[tb + T_SRC_VAL] = source_value_tran(Pv, s, pl.wave[e], pl.waveN[e], t, pl.k.pi);
         } else if (kind == CSIM_C) {
             const double vPrev = volt_of(xp, q[0]) - volt_of(xp, q[1]);
             T[tb + T_C_IH] = -T[tb + T_C_GC] * vPrev;              // tanalisis.cpp:77

@@ -61,7 +61,7 @@ int fillGenPlan(csim_engine* eng, const csim::GatherPlan& g, csim::GenPlan& out)
     out.hasNonlinear = ir->has_nonlinear;
     out.pad = 0;
     out.kind = eng->dKind; out.eq = eng->dEq; out.branch = eng->dBranch;
-    out.slot = eng->dSlot; out.wave = eng->dWave; out.termBase = eng->dTermBase;
+    out.slot = eng->dSlot; out.wave = eng->dWave; out.waveN = eng->dWaveN; out.termBase = eng->dTermBase;
     int rc;
     if ((rc = upload(eng, g.gPtr, &out.gPtr))) return rc;
     if ((rc = upload(eng, g.gPos, &out.gPos))) return rc;
@@ -203,6 +203,7 @@ int csim_engine_create(const csim_netlist* nl, int32_t device, csim_engine** out
     if (!rc) rc = upload(eng, c.branchEq, &eng->dBranch);
     if (!rc) rc = upload(eng, c.paramSlot, &eng->dSlot);
     if (!rc) rc = upload(eng, c.wave, &eng->dWave);
+    if (!rc) rc = upload(eng, c.waveN, &eng->dWaveN);
     if (!rc) rc = upload(eng, eng->plan.termBase, &eng->dTermBase);
     if (!rc) rc = upload(eng, c.mcKind, &eng->dMcKind);
     if (!rc) rc = upload(eng, c.nominal, &eng->dNominal);

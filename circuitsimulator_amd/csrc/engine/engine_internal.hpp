@@ -20,7 +20,7 @@ struct csim_engine {
 
     // element tables (shared by both gather plans)
     const int32_t *dKind = nullptr, *dEq = nullptr, *dBranch = nullptr, *dSlot = nullptr,
-                  *dWave = nullptr, *dTermBase = nullptr;
+                  *dWave = nullptr, *dWaveN = nullptr, *dTermBase = nullptr;
     csim::GenPlan gpDc{}, gpTran{};
 
     // Monte-Carlo recipe

@@ -26,7 +26,9 @@
  *        R   : [R]
  *        C   : [C]
  *        L   : [L]
- *        V, I: [dc, v0, va, freq, td, phi]      (SourceSpec, include/sim.hpp:146)
+ *        V, I: NONE/SIN [dc, v0, va, freq, td, phi]      (SourceSpec, include/sim.hpp:146)
+ *              PULSE    [dc, v1, v2, td, tr, tf, ton, per] (PulseSpec, include/sim.hpp:46-54)
+ *              PWL      [dc, t_0..t_{n-1}, v_0..v_{n-1}], n = wave_n[e]  (PwlSpec, :64-67)
  *        MOS : [Vth, K, lambda, Cj0]            (MosfetBase, include/element.hpp:134)
  *   - batched parameter tables are slot-major:  params[p * B + b].
  */
@@ -49,17 +51,22 @@ enum csim_elem_kind {
     CSIM_PMOS  = 6
 };
 
-/* transient waveform attached to a V/I source (include/sim.hpp:25-30).
- * Only NONE and SIN are produced by the netlist dialect (src/parser.cpp:346-351). */
+/* transient waveform attached to a V/I source (include/sim.hpp:25-30, evaluated by
+ * TranWaveform::eval :75-143).  The reference's parser only produces NONE and SIN
+ * (src/parser.cpp:346-351); PULSE and PWL are reachable through its C++ API and are accepted
+ * by this repository's netlist dialect as a superset. */
 enum csim_wave_kind {
-    CSIM_WAVE_NONE = 0,
-    CSIM_WAVE_SIN  = 2
+    CSIM_WAVE_NONE  = 0,
+    CSIM_WAVE_PULSE = 1,
+    CSIM_WAVE_SIN   = 2,
+    CSIM_WAVE_PWL   = 3
 };
 
 #define CSIM_PARAMS_R     1
 #define CSIM_PARAMS_C     1
 #define CSIM_PARAMS_L     1
-#define CSIM_PARAMS_SRC   6
+#define CSIM_PARAMS_SRC   6       /* NONE / SIN sources */
+#define CSIM_PARAMS_PULSE 8
 #define CSIM_PARAMS_MOS   4
 
 /* literal constants of the hot path.  Kept in the IR
@@ -103,6 +110,7 @@ typedef struct csim_ir {
     const int32_t* branch_eq; /* V, L: branch equation; others -1             */
     const int32_t* param_slot;/* first slot in P                              */
     const int32_t* wave;      /* V, I: csim_wave_kind; others 0               */
+    const int32_t* wave_n;    /* PWL sources: number of (t, v) points; else 0 */
 
     csim_consts k;
 } csim_ir;

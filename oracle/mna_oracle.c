@@ -134,8 +134,10 @@ unsigned oracle_solve_lu(int n, const double* A, const double* b, double* x)
 }
 
 /* ------------------------------------------------------------------ *
- * sources                          include/sim.hpp:117-122, 146-163
+ * sources                          include/sim.hpp:75-143, 146-163
  * ------------------------------------------------------------------ */
+static double clamp01_(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }   /* utils.hpp:80-84 */
+
 static double src_eval_dc(const csim_ir* ir, int e, const double* params, int64_t pstride, double scale)
 {
     const int s = ir->param_slot[e];
@@ -158,6 +160,43 @@ static double src_eval_tran(const csim_ir* ir, int e, const double* params, int6
             double om = 2.0 * ir->k.pi * freq;              /* :120 */
             w = v0 + va * sin(om * tau + phi);              /* :121 */
         }
+    } else if (ir->wave[e] == CSIM_WAVE_PULSE) {            /* :80-115 */
+        const double v1 = P_(s + 1), v2 = P_(s + 2), td = P_(s + 3), tr = P_(s + 4), tf = P_(s + 5);
+        const double ton = P_(s + 6), per = P_(s + 7);
+        if (per <= 0.0) {                                   /* single shot */
+            double tau = t - td;
+            if (tau <= 0.0) w = v1;
+            else if (tau < tr) { double k = clamp01_(tau / tr); w = v1 + k * (v2 - v1); }
+            else if (tau < tr + ton) w = v2;
+            else { double tfall = tau - (tr + ton); double k = clamp01_(tfall / tf); w = v2 + k * (v1 - v2); }
+        } else if (t < td) {
+            w = v1;
+        } else {                                            /* periodic */
+            double tau = fmod(t - td, per);
+            if (tau < 0.0) tau += per;
+            if (tau < tr) { double k = clamp01_(tau / tr); w = v1 + (v2 - v1) * k; }
+            else if (tau < tr + ton) w = v2;
+            else if (tau < tr + ton + tf) { double tfall = tau - (tr + ton); double k = clamp01_(tfall / tf); w = v2 + (v1 - v2) * k; }
+            else w = v1;
+        }
+    } else if (ir->wave[e] == CSIM_WAVE_PWL) {              /* :124-138 */
+        const int n = ir->wave_n[e];
+        #define PT_(i) P_(s + 1 + (i))
+        #define PV_(i) P_(s + 1 + n + (i))
+        if (n <= 0) w = 0.0;
+        else if (t <= PT_(0)) w = PV_(0);
+        else if (t >= PT_(n - 1)) w = PV_(n - 1);
+        else {
+            w = PV_(n - 1);
+            for (int i = 0; i + 1 < n; ++i)
+                if (t > PT_(i) && t <= PT_(i + 1)) {
+                    double k = (t - PT_(i)) / (PT_(i + 1) - PT_(i));
+                    w = PV_(i) + (PV_(i + 1) - PV_(i)) * k;
+                    break;
+                }
+        }
+        #undef PT_
+        #undef PV_
     }
     return dc + w;                                          /* :161 */
 }

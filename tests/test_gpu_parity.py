@@ -736,3 +736,42 @@ def test_batch4096_every_instance_against_the_oracle(engines, torch_mod):
         assert r["iters"][b] == o["iters"], b
         worst = max(worst, rel_err(r["x"][:, b], o["x_final"], nl.n_node_eq).max())
     assert worst < TOL, worst
+
+
+# ------------------------------------------------- PULSE / PWL sources
+
+def test_pulse_pwl_sources_general_and_scheduled(torch_mod, tmp_path, monkeypatch):
+    """TranWaveform::eval PULSE / PWL (reference include/sim.hpp:80-138) on V and I sources: the
+    general kernel, the JIT-generated scheduled kernel and the host API against the oracle."""
+    from circuitsimulator_amd import Engine, Netlist
+    monkeypatch.setenv("CSIM_JIT_DIR", str(tmp_path / "jit"))
+    nl = Netlist.from_file(netlist_path("pulse_pwl.sp"))
+    eng = Engine(nl, 0)
+    assert eng.tran_kernel == "general"
+    B, steps = 70, 400
+    params = eng.mc_params(99, 0.05, 0, B)
+    probes = [nl.eq_names.index(n) for n in ("101", "110", "104", "111", "120")]
+    slow = _run_tran(torch_mod, eng, params, steps, nl.tstep, probes=probes, want_step_iters=True)
+    ph = params.cpu().numpy()
+    orc = _orc()
+    for b in (0, 33, 69):
+        o = orc.tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstop, want_step_iters=True)
+        assert o["n_steps"] == steps
+        assert np.array_equal(slow["step_iters"][:, b], o["step_iters"])
+        assert slow["status"][b] == o["status"] == 0
+        want = o["rows"][:, [1 + q for q in probes]]
+        assert rel_err(slow["wave"][:, :, b], want, nl.n_node_eq).max() < TOL
+        assert rel_err(slow["x"][:, b], o["x_final"], nl.n_node_eq).max() < TOL
+    eng.jit_scheduled(params, plan_steps=steps)
+    assert eng.tran_kernel == "scheduled"
+    fast = _run_tran(torch_mod, eng, params, steps, nl.tstep, probes=probes, want_step_iters=True)
+    assert np.array_equal(fast["step_iters"], slow["step_iters"])
+    assert np.array_equal(fast["status"] & NOFB, slow["status"])
+    assert rel_err(fast["wave"].transpose(2, 0, 1).reshape(-1, len(probes)),
+                   slow["wave"].transpose(2, 0, 1).reshape(-1, len(probes)), nl.n_node_eq).max() < TOL
+    assert ((fast["status"] & FALLBACK) != 0).sum() < B // 2
+    # host API, nominal instance: every CSV column
+    wave, xf, it, st = eng.tran_host(B=1, probes=list(range(nl.n_unknowns)))
+    o = orc.tran(nl.ir_ptr, nl.n_unknowns, nl.nominal_params, 0, nl.tstep, nl.tstop)
+    assert it[0] == o["iters"] and st[0] & NOFB == 0
+    assert rel_err(wave[0], o["rows"][:, 1:], nl.n_node_eq).max() < TOL
