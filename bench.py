@@ -54,14 +54,21 @@ def hbm_traffic_per_launch(nl, kernel, B, S):
     return ent["bytes_per_launch"] if ent else None
 
 
-def cpu_baseline(nl, params_host, n_inst, tstep, n_tsteps):
-    """Oracle (CPU restatement, 1 thread) on a bounded sample of the same workload."""
+def cpu_baseline(nl, params_host, n_inst, tstep, n_tsteps, threads=1):
+    """Oracle (CPU restatement) on a bounded sample of the same workload: instances 0..n_inst-1,
+    one instance per call, `threads` host threads over instances (the C call releases the GIL)."""
     from oracle import binding as orc
+
+    def one(b):
+        return orc.tran(nl.ir_ptr, nl.n_unknowns, params_host, b, tstep, tstep * n_tsteps, want_rows=False)["iters"]
+
     t0 = time.perf_counter()
-    iters = 0
-    for b in range(n_inst):
-        r = orc.tran(nl.ir_ptr, nl.n_unknowns, params_host, b, tstep, tstep * n_tsteps, want_rows=False)
-        iters += r["iters"]
+    if threads <= 1:
+        iters = sum(one(b) for b in range(n_inst))
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(threads) as pool:
+            iters = sum(pool.map(one, range(n_inst)))
     dt = time.perf_counter() - t0
     return iters, dt
 
@@ -82,6 +89,7 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "general", "scheduled"])
     ap.add_argument("--cpu-iters", type=float, default=3.0e6, help="approx. NR iterations of the CPU sample (~15 s)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the all-cores CPU leg (1 = skip it)")
     ap.add_argument("--large-batch", type=int, default=65536,
                     help="also time this many instances per GPU (one wave per SIMD needs >= 65536); 0 = skip")
     args = ap.parse_args()
@@ -257,6 +265,15 @@ def main():
                           "point (%d NR iterations, %.1f s, host has %d cores)"
                           % (n_cpu - 1, s_cpu, ci, cdt, os.cpu_count() or 0),
             }
+            # the same port on all host cores (threads over instances), a second bounded sample
+            nthr = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), args.cpu_threads))
+            if nthr > 1:
+                n_mt = int(min(ph.shape[1], n_cpu * nthr))
+                mi, mdt = cpu_baseline(nl, ph, n_mt, tstep, s_cpu, threads=nthr)
+                rec["cpu_baseline"]["all_cores"] = {
+                    "value": mi / mdt, "cores": nthr,
+                    "sample": "instances 0..%d, %d time steps (%d NR iterations, %.1f s)" % (n_mt - 1, s_cpu, mi, mdt),
+                }
         print(json.dumps(rec))
 
     import torch.distributed as dist
