@@ -163,7 +163,7 @@ def main():
     local_iters = int((iters - it_before).sum().item())
     total_iters = shard.all_reduce_sum(float(local_iters), device=dev)
     wall_max = shard.all_reduce_max(wall, device=dev)
-    n_bad = int((status & 0x27).ne(0).sum().item())           # non-finite / non-converged / tiny pivot / fallback
+    n_bad = int((status & 0xA7).ne(0).sum().item())           # non-finite / non-converged / tiny pivot / fallback
     n_bad = int(shard.all_reduce_sum(float(n_bad), device=dev))
 
     # ---- gather of node voltages (probes of the netlist: V(102), V(103)) -----
@@ -198,7 +198,7 @@ def main():
         il = shard.all_reduce_sum(float((itl - before).sum().item()), device=dev)
         large = {"batch_per_gpu": BL, "value": il / wl, "steps": nl_steps,
                  "kernel_avg_ms": e0.elapsed_time(e1) / nl_steps,
-                 "flagged_instances": int((stl & 0x27).ne(0).sum().item())}
+                 "flagged_instances": int((stl & 0xA7).ne(0).sum().item())}
         del pl, xl, itl, stl
 
     if rank == 0:

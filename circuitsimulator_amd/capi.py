@@ -27,6 +27,7 @@ ST_LU_TINY_PIVOT = 0x0004
 ST_DC_NONCONV = 0x0008
 ST_DC_NONFINITE = 0x0010
 ST_SCHED_FALLBACK = 0x0020
+ST_SCHED_FALLBACK_DC = 0x0080
 ST_LU_ZERO_DIAG = 0x0040
 
 # every symbol include/csim.h declares: name -> (restype, argtypes)
@@ -71,6 +72,7 @@ PROTOTYPES = {
     "csim_engine_jit_scheduled": (C.c_int, [_vp, _vp, _i32, _dbl, _i64]),
     "csim_record_pivot_schedules": (C.c_int, [_vp, _vp, _i32, _i32, _dbl, _i64, _i32, _vp, _vp, _pi32,
                                               C.POINTER(C.c_int64)]),
+    "csim_record_dc_pivot_schedules": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _pi32, C.POINTER(C.c_int64)]),
     "csim_record_pivot_schedule": (C.c_int, [_vp, _vp, _i32, _i32, _dbl, _i64, _vp, C.POINTER(C.c_int64),
                                              C.POINTER(C.c_int64)]),
 }

@@ -52,6 +52,7 @@ std::string PivotSchedule::str() const
 bool ScheduleSet::parse(const std::string& text, int N, ScheduleSet& out)
 {
     out.alts.clear();
+    out.dcAlts.clear();
     std::size_t i = 0;
     while (i <= text.size()) {
         std::size_t e = text.find('\n', i);
@@ -69,12 +70,23 @@ bool ScheduleSet::parse(const std::string& text, int N, ScheduleSet& out)
             bool blank = true, dash = false;
             for (char ch : body) { blank = blank && (ch == ' ' || ch == '\t' || ch == '\r' || ch == ','); dash = dash || ch == '-'; }
             if (blank) continue;
+            bool isDc = false;                                        // "dc <schedule>"
+            {
+                std::size_t w = 0;
+                while (w < body.size() && (body[w] == ' ' || body[w] == '\t')) ++w;
+                if (w + 2 <= body.size() && (body[w] == 'd' || body[w] == 'D') && (body[w + 1] == 'c' || body[w + 1] == 'C') &&
+                    (w + 2 == body.size() || body[w + 2] == ' ' || body[w + 2] == '\t')) {
+                    isDc = true;
+                    body = body.substr(w + 2);
+                }
+            }
             if (dash) for (char& ch : body) if (ch == '-') ch = ' ';  // "-" = no swaps
             PivotSchedule one;
             if (!PivotSchedule::parse(body, N, one)) return false;
+            std::vector<PivotSchedule>& dst = isDc ? out.dcAlts : out.alts;
             bool dup = false;
-            for (const PivotSchedule& a : out.alts) dup = dup || a.pivotPos == one.pivotPos;
-            if (!dup) out.alts.push_back(one);
+            for (const PivotSchedule& a : dst) dup = dup || a.pivotPos == one.pivotPos;
+            if (!dup) dst.push_back(one);
         }
     }
     return !out.alts.empty();
@@ -84,6 +96,7 @@ std::string ScheduleSet::str() const
 {
     std::string o;
     for (std::size_t a = 0; a < alts.size(); ++a) o += (a ? " ; " : "") + (alts[a].str().empty() ? std::string("-") : alts[a].str());
+    for (std::size_t a = 0; a < dcAlts.size(); ++a) o += " ; dc " + (dcAlts[a].str().empty() ? std::string("-") : dcAlts[a].str());
     return o;
 }
 
@@ -93,6 +106,10 @@ uint64_t scheduleHash(const csim_ir& ir, const ScheduleSet& set)
     for (std::size_t a = 1; a < set.alts.size(); ++a) {
         h ^= 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
         for (int p : set.alts[a].pivotPos) { h ^= static_cast<uint64_t>(p + 1); h *= 1099511628211ull; }
+    }
+    for (std::size_t a = 0; a < set.dcAlts.size(); ++a) {
+        h ^= 0xD1B54A32D192ED03ull + (h << 6) + (h >> 2);
+        for (int p : set.dcAlts[a].pivotPos) { h ^= static_cast<uint64_t>(p + 1); h *= 1099511628211ull; }
     }
     return h;
 }
@@ -267,6 +284,7 @@ struct VariantOptions {
     bool stepInLds;     // per-step terms (sources, history currents) in LDS (else registers)
     int parkBudget;     // how many finished U-row values may be parked in LDS (-1 = all)
     int ckUnroll = 4;   // unroll factor of the per-step checkpoint loop (swept 1/2/4/8/31: 4 best, 31 pins 2N VGPRs)
+    bool dcMode = false;// emit the DC operating-point kernel (source ramp + ConvController) instead of the transient
 };
 
 // emits ONE __global__ kernel; returns the number of LDS doubles per lane it uses
@@ -301,9 +319,10 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         const int tb = ap.termBase[static_cast<std::size_t>(e)];
         switch (ir.kind[e]) {
             case CSIM_V: case CSIM_I: stepSlot[static_cast<std::size_t>(tb + T_SRC_VAL)] = nStep++; break;
-            case CSIM_C: stepSlot[static_cast<std::size_t>(tb + T_C_IH)] = nStep++; break;
-            case CSIM_L: stepSlot[static_cast<std::size_t>(tb + T_L_VH)] = nStep++; break;
+            case CSIM_C: if (!opt.dcMode) stepSlot[static_cast<std::size_t>(tb + T_C_IH)] = nStep++; break;
+            case CSIM_L: if (!opt.dcMode) stepSlot[static_cast<std::size_t>(tb + T_L_VH)] = nStep++; break;
             case CSIM_NMOS: case CSIM_PMOS:
+                if (opt.dcMode) break;
                 for (int o = T_M_IHGS; o <= T_M_IHDB; ++o) stepSlot[static_cast<std::size_t>(tb + o)] = nStep++;
                 break;
             default: break;
@@ -345,8 +364,8 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         const int sl = ir.param_slot[e], tb = ap.termBase[static_cast<std::size_t>(e)];
         switch (ir.kind[e]) {
             case CSIM_R: toLdsTerm(tb + T_R_G); break;
-            case CSIM_C: toLdsTerm(tb + T_C_GC); break;
-            case CSIM_L: toLdsTerm(tb + T_L_REQ); break;
+            case CSIM_C: if (!opt.dcMode) toLdsTerm(tb + T_C_GC); break;
+            case CSIM_L: if (!opt.dcMode) toLdsTerm(tb + T_L_REQ); break;
             case CSIM_V: case CSIM_I:
                 for (int o = 0, cnt = (e + 1 < ir.n_elems ? ir.param_slot[e + 1] : ir.n_params) - sl; o < cnt; ++o) {
                     toLdsParam(sl + o);
@@ -359,28 +378,43 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
                 }
                 break;
             case CSIM_NMOS: case CSIM_PMOS:
-                toLdsTerm(tb + T_M_GCH); toLdsTerm(tb + T_M_GCF);
+                if (!opt.dcMode) { toLdsTerm(tb + T_M_GCH); toLdsTerm(tb + T_M_GCF); }
                 for (int o = 0; o < 3; ++o) toLdsParam(sl + o);
                 break;
             default: break;
         }
     }
 
-    src << "extern \"C\" __global__ void __launch_bounds__(64)\n"
-        << opt.kernelName << "(const double* __restrict__ params, int B, double dt, long long stepFirst,\n"
-        << "                       long long nSteps, const int* __restrict__ probeEq, int nProbe, int outStride,\n"
-        << "                       double* __restrict__ wave, double* __restrict__ xio, long long* __restrict__ iters,\n"
-        << "                       unsigned* __restrict__ status, int* __restrict__ stepIters,\n"
-        << "                       unsigned char* __restrict__ fallback, int* __restrict__ done)\n{\n"
-        << "    __shared__ double lds[@LDS_DOUBLES@ * 64];\n"
-        << "    const int lane = threadIdx.x;\n"
-        << "    const int b = blockIdx.x * 64 + threadIdx.x;\n"
-        << "    const bool inb = b < B;\n"
-        << "    const long long bb = inb ? b : B - 1;      // out-of-range lanes shadow the last instance, never store\n"
-        << "    const long long SB = B;\n"
-        << "    const bool splitFlag = outStride < 0;      // never true (the engine rejects it); opaque to the compiler\n"
-        << "    // hand-back launches: nothing to do for this wave unless one of its instances is unfinished\n"
-        << "    if (!__any(inb && done[bb] < nSteps)) return;\n";
+    if (opt.dcMode) {
+        src << "extern \"C\" __global__ void __launch_bounds__(64)\n"
+            << opt.kernelName << "(const double* __restrict__ params, int B, double* __restrict__ xout,\n"
+            << "                       int* __restrict__ iters, unsigned* __restrict__ status,\n"
+            << "                       unsigned char* __restrict__ fallback)\n{\n"
+            << "    __shared__ double lds[@LDS_DOUBLES@ * 64];\n"
+            << "    const int lane = threadIdx.x;\n"
+            << "    const int b = blockIdx.x * 64 + threadIdx.x;\n"
+            << "    const bool inb = b < B;\n"
+            << "    const long long bb = inb ? b : B - 1;      // out-of-range lanes shadow the last instance, never store\n"
+            << "    const long long SB = B;\n"
+            << "    const bool splitFlag = B < 0;              // never true; opaque to the compiler\n";
+    } else {
+        src << "extern \"C\" __global__ void __launch_bounds__(64)\n"
+            << opt.kernelName << "(const double* __restrict__ params, int B, double dt, long long stepFirst,\n"
+            << "                       long long nSteps, const int* __restrict__ probeEq, int nProbe, int outStride,\n"
+            << "                       double* __restrict__ wave, double* __restrict__ xio, long long* __restrict__ iters,\n"
+            << "                       unsigned* __restrict__ status, int* __restrict__ stepIters,\n"
+            << "                       unsigned char* __restrict__ fallback, int* __restrict__ done)\n{\n"
+            << "    __shared__ double lds[@LDS_DOUBLES@ * 64];\n"
+            << "    const int lane = threadIdx.x;\n"
+            << "    const int b = blockIdx.x * 64 + threadIdx.x;\n"
+            << "    const bool inb = b < B;\n"
+            << "    const long long bb = inb ? b : B - 1;      // out-of-range lanes shadow the last instance, never store\n"
+            << "    const long long SB = B;\n"
+            << "    const bool splitFlag = outStride < 0;      // never true (the engine rejects it); opaque to the compiler\n"
+            << "    // hand-back launches: nothing to do for this wave unless one of its instances is unfinished\n"
+            << "    if (!__any(inb && done[bb] < nSteps)) return;\n";
+
+    }
 
     // ---- parameters
     for (int p = 0; p < ir.n_params; ++p) {
@@ -397,13 +431,16 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
                 src << "    const double " << tname(tb + T_R_G) << " = (" << pname(s) << " == 0.0) ? 0.0 : 1.0 / " << pname(s) << ";\n";
                 break;
             case CSIM_C:
+                if (opt.dcMode) break;                      // open circuit at DC
                 src << "    const double " << tname(tb + T_C_GC) << " = (" << pname(s) << " > 0.0 && dt > 0.0) ? " << pname(s) << " / dt : 0.0;\n";
                 break;
             case CSIM_L:
+                if (opt.dcMode) break;                      // 0 V source at DC: constant incidence only
                 src << "    const double " << tname(tb + T_L_REQ) << " = " << pname(s) << " / dt;\n"
                     << "    viol = viol || !(" << pname(s) << " > 0.0);   // incidence +-1 folded as constants\n";
                 break;
             case CSIM_NMOS: case CSIM_PMOS:
+                if (opt.dcMode) break;                      // no junction capacitors at DC
                 src << "    const double ch" << e << " = 0.5 * " << pname(s + 3) << ";\n"
                     << "    const double " << tname(tb + T_M_GCH) << " = (ch" << e << " > 0.0 && dt > 0.0) ? ch" << e << " / dt : 0.0;\n"
                     << "    const double " << tname(tb + T_M_GCF) << " = (" << pname(s + 3) << " > 0.0 && dt > 0.0) ? " << pname(s + 3) << " / dt : 0.0;\n";
@@ -411,38 +448,54 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             default: break;
         }
     }
-    src << "    const double " << tname(ap.termGmin) << " = " << lit(K.tran_gmin) << ";\n";
+    if (!opt.dcMode) src << "    const double " << tname(ap.termGmin) << " = " << lit(K.tran_gmin) << ";\n";
+    else termAV[static_cast<std::size_t>(ap.termGmin)] = AV::dyn("gminv");      // ConvController's gmin, per iteration
     src << ldsInit.str();
 
     // ---- state
-    src << "    {\n        const double* xin = xio + bb;\n#pragma unroll 1\n"
-        << "        for (int i = 0; i < " << N << "; ++i, xin += SB) X(i) = *xin;\n    }\n";
-    src << "    unsigned st = inb ? status[bb] : 0u;\n"
-        << "    bool dead = !inb || (st & ST_TRAN_NONFINITE) != 0u;   // the reference would have thrown: stay stopped\n"
-        << "    long long itTotal = 0;\n"
-        << "    // steps of this launch already completed for this instance (hybrid stepping: after a schedule\n"
-        << "    // violation the general kernel advances the instance a few steps and hands it back)\n"
-        << "    long long sdone = (inb && !dead) ? (long long)done[bb] : nSteps;\n"
-        << "    if (stepFirst == 0 && sdone == 0 && wave && inb) {\n"
-        << "        for (int q = 0; q < nProbe; ++q) wave[((long long)q) * SB + b] = X(probeEq[q]);\n"
-        << "    }\n\n"
-        << "    // the step counter stays wave-uniform (scalar registers): start at the least advanced lane's next\n"
-        << "    // step; a lane takes part in step s when s is ITS next step (lanes handed back by the general\n"
-        << "    // kernel may be ahead of or behind their wave-mates)\n"
-        << "    int smin = (int)(sdone < nSteps ? sdone + 1 : nSteps + 1);\n"
-        << "    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(smin, m); smin = o < smin ? o : smin; }\n"
-        << "    smin = __builtin_amdgcn_readfirstlane(smin);\n"
-        << "    for (long long s = smin; s <= nSteps; ++s) {\n"
-        << "        if (!__any(!dead && !viol && sdone < nSteps)) break;\n"
-        << "        const bool live = !dead && !viol && sdone + 1 == s;\n"
-        << "        const long long gstep = stepFirst + s;\n"
-        << "        const double tNow = (double)(int)gstep * dt;\n"
-        << "        if (live) {     // checkpoint: state at the start of this step.  A ROLLED loop: unrolled,\n"
-        << "                        // hipcc hoists the N store addresses out of the time loop and pins 2N VGPRs\n"
-        << "            double* ck = xio + b;\n"
-        << "#pragma unroll " << opt.ckUnroll << "\n"
-        << "            for (int i = 0; i < " << N << "; ++i, ck += SB) *ck = X(i);\n"
-        << "        }\n";
+    if (opt.dcMode) {
+        // dcSolveNewtonLU (reference src/dcanalysis.cpp:95-163): x = 0, sources ramped in dc_ramp_steps
+        // steps, damped Newton with the ConvController's adaptive gmin in each
+        src << "#pragma unroll 1\n    for (int i = 0; i < " << N << "; ++i) X(i) = 0.0;\n"
+            << "    unsigned st = 0u;\n    int itTotal = 0;\n"
+            << "    for (int step = 1; step <= " << K.dc_ramp_steps << "; ++step) {\n"
+            << "        if (!__any(inb && !viol)) break;\n"
+            << "        const double scale = (double)step / " << K.dc_ramp_steps << ";\n"
+            << "        // baseGmin(scale) (dcanalysis.hpp:45-48), every product and sum rounded separately\n"
+            << "        const double gb = __dadd_rn(__dmul_rn(" << lit(K.gmin_high) << ", 1.0 - scale), __dmul_rn(" << lit(K.gmin_low) << ", scale));\n"
+            << "        double gminv = gb;\n"
+            << "        double prevErr = INFINITY;\n";
+    } else {
+        src << "    {\n        const double* xin = xio + bb;\n#pragma unroll 1\n"
+            << "        for (int i = 0; i < " << N << "; ++i, xin += SB) X(i) = *xin;\n    }\n";
+        src << "    unsigned st = inb ? status[bb] : 0u;\n"
+            << "    bool dead = !inb || (st & ST_TRAN_NONFINITE) != 0u;   // the reference would have thrown: stay stopped\n"
+            << "    long long itTotal = 0;\n"
+            << "    // steps of this launch already completed for this instance (hybrid stepping: after a schedule\n"
+            << "    // violation the general kernel advances the instance a few steps and hands it back)\n"
+            << "    long long sdone = (inb && !dead) ? (long long)done[bb] : nSteps;\n"
+            << "    if (stepFirst == 0 && sdone == 0 && wave && inb) {\n"
+            << "        for (int q = 0; q < nProbe; ++q) wave[((long long)q) * SB + b] = X(probeEq[q]);\n"
+            << "    }\n\n"
+            << "    // the step counter stays wave-uniform (scalar registers): start at the least advanced lane's next\n"
+            << "    // step; a lane takes part in step s when s is ITS next step (lanes handed back by the general\n"
+            << "    // kernel may be ahead of or behind their wave-mates)\n"
+            << "    int smin = (int)(sdone < nSteps ? sdone + 1 : nSteps + 1);\n"
+            << "    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(smin, m); smin = o < smin ? o : smin; }\n"
+            << "    smin = __builtin_amdgcn_readfirstlane(smin);\n"
+            << "    for (long long s = smin; s <= nSteps; ++s) {\n"
+            << "        if (!__any(!dead && !viol && sdone < nSteps)) break;\n"
+            << "        const bool live = !dead && !viol && sdone + 1 == s;\n"
+            << "        const long long gstep = stepFirst + s;\n"
+            << "        const double tNow = (double)(int)gstep * dt;\n"
+            << "        if (live) {     // checkpoint: state at the start of this step.  A ROLLED loop: unrolled,\n"
+            << "                        // hipcc hoists the N store addresses out of the time loop and pins 2N VGPRs\n"
+            << "            double* ck = xio + b;\n"
+            << "#pragma unroll " << opt.ckUnroll << "\n"
+            << "            for (int i = 0; i < " << N << "; ++i, ck += SB) *ck = X(i);\n"
+            << "        }\n";
+
+    }
 
     // ---- per-step terms (device_common.hpp terms_step_tran), stored to LDS or kept in registers
     const std::string i2 = "        ";
@@ -454,7 +507,13 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         const int32_t* q = ir.eq + 4 * e;
         switch (ir.kind[e]) {
             case CSIM_V: case CSIM_I:
-                if (ir.wave[e] == CSIM_WAVE_SIN) {
+                if (opt.dcMode) {
+                    // SourceSpec::evalDC (reference include/sim.hpp:152-158): (dc + (SIN ? v0 : 0)) * scale
+                    if (ir.wave[e] == CSIM_WAVE_SIN)
+                        src << i2 << sname(tb) << " = (" << pRef[static_cast<std::size_t>(s)] << " + " << pRef[static_cast<std::size_t>(s + 1)] << ") * scale;\n";
+                    else
+                        src << i2 << sname(tb) << " = " << pRef[static_cast<std::size_t>(s)] << " * scale;\n";
+                } else if (ir.wave[e] == CSIM_WAVE_SIN) {
                     src << i2 << "if (tNow < " << pRef[static_cast<std::size_t>(s + 4)] << ") " << sname(tb) << " = " << pRef[static_cast<std::size_t>(s)] << " + " << pRef[static_cast<std::size_t>(s + 1)] << ";\n"
                         << i2 << "else " << sname(tb) << " = " << pRef[static_cast<std::size_t>(s)] << " + (" << pRef[static_cast<std::size_t>(s + 1)] << " + " << pRef[static_cast<std::size_t>(s + 2)]
                         << " * sin((2.0 * " << lit(K.pi) << " * " << pRef[static_cast<std::size_t>(s + 3)] << ") * (tNow - " << pRef[static_cast<std::size_t>(s + 4)] << ") + "
@@ -507,12 +566,15 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
                 }
                 break;
             case CSIM_C:
+                if (opt.dcMode) break;
                 src << i2 << sname(tb + T_C_IH) << " = -" << tRef[static_cast<std::size_t>(tb + T_C_GC)] << " * " << vdiff(q[0], q[1]) << ";\n";
                 break;
             case CSIM_L:
+                if (opt.dcMode) break;
                 src << i2 << sname(tb + T_L_VH) << " = -" << tRef[static_cast<std::size_t>(tb + T_L_REQ)] << " * X(" << ir.branch_eq[e] << ");\n";
                 break;
             case CSIM_NMOS: case CSIM_PMOS:
+                if (opt.dcMode) break;
                 src << i2 << sname(tb + T_M_IHGS) << " = -" << tRef[static_cast<std::size_t>(tb + T_M_GCH)] << " * " << vdiff(q[1], q[2]) << ";\n"
                     << i2 << sname(tb + T_M_IHGD) << " = -" << tRef[static_cast<std::size_t>(tb + T_M_GCH)] << " * " << vdiff(q[1], q[0]) << ";\n"
                     << i2 << sname(tb + T_M_IHSB) << " = -" << tRef[static_cast<std::size_t>(tb + T_M_GCF)] << " * " << vdiff(q[2], q[3]) << ";\n"
@@ -522,10 +584,15 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         }
     }
 
-    src << i2 << "bool active = live;\n"
-        << i2 << "int it = 0;\n"
-        << i2 << "for (int iter = 0; iter < " << K.tran_max_iters << "; ++iter) {\n"
-        << i2 << "    if (!__any(active)) break;\n";
+    if (opt.dcMode)
+        src << i2 << "bool active = inb && !viol;\n"
+            << i2 << "for (int iter = 0; iter < " << K.dc_max_iters << "; ++iter) {\n"
+            << i2 << "    if (!__any(active)) break;\n";
+    else
+        src << i2 << "bool active = live;\n"
+            << i2 << "int it = 0;\n"
+            << i2 << "for (int iter = 0; iter < " << K.tran_max_iters << "; ++iter) {\n"
+            << i2 << "    if (!__any(active)) break;\n";
     // ---- per-iteration terms: MOS channel (device_common.hpp mos_eval)
     std::vector<char> xLoaded(static_cast<std::size_t>(N), 0);
     for (int e = 0; e < ir.n_elems; ++e) {
@@ -579,7 +646,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         std::vector<std::vector<AV>> M(static_cast<std::size_t>(N), std::vector<AV>(static_cast<std::size_t>(N + 1)));
         g.out << g.ind << "// assembly (lazy) + elimination\n";
         g.pending.assign(static_cast<std::size_t>(N), std::vector<std::vector<AV>>(static_cast<std::size_t>(N + 1)));
-        const GatherPlan& gp = ap.tran;
+        const GatherPlan& gp = opt.dcMode ? ap.dc : ap.tran;
         for (int n = 0; n < gp.nnzG(); ++n) {
             std::vector<AV> terms;
             for (int c = gp.gPtr[static_cast<std::size_t>(n)]; c < gp.gPtr[static_cast<std::size_t>(n + 1)]; ++c) {
@@ -743,12 +810,13 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
     // ---- the alternatives are tried in order; lanes whose checks failed take the next one
     g.out << g.ind << "bool pv = false;     // every schedule tried so far failed its pivot checks\n";
     for (int i = 0; i < N; ++i) g.out << g.ind << "double xr" << i << ";\n";
-    for (std::size_t alt = 0; alt < set.alts.size(); ++alt) {
+    const std::vector<PivotSchedule>& alternatives = opt.dcMode ? set.dcAlts : set.alts;
+    for (std::size_t alt = 0; alt < alternatives.size(); ++alt) {
         const std::string pvName = "pvA" + std::to_string(alt);
         if (alt == 0) g.out << g.ind << "{\n";
         else g.out << g.ind << "if (__any(active && pv)) {   // alternative schedule " << alt << "\n";
         g.out << g.ind << "bool " << pvName << " = false;\n";
-        const std::vector<AV> sol = emitSolve(set.alts[alt], pvName);
+        const std::vector<AV> sol = emitSolve(alternatives[alt], pvName);
         for (int i = 0; i < N; ++i) {
             if (alt == 0) g.out << g.ind << "xr" << i << " = " << g.ref(sol[static_cast<std::size_t>(i)]) << ";\n";
             else g.out << g.ind << "xr" << i << " = pv ? " << g.ref(sol[static_cast<std::size_t>(i)]) << " : xr" << i << ";\n";
@@ -759,50 +827,95 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
     }
     ldsNext = ldsMax;
 
-    // ---- damped update, norm in index order, convergence (tanalisis.cpp:360-376)
-    std::ostringstream& o = g.out;
-    o << g.ind << "double ss = 0.0;\n";
-    for (int i = 0; i < N; ++i) {
-        o << g.ind << "const double xo" << i << " = X(" << i << ");\n"
-          << g.ind << "const double xn" << i << " = xo" << i << " + " << lit(K.tran_alpha) << " * (xr" << i << " - xo" << i << ");\n"
-          << g.ind << "{ const double d = xn" << i << " - xo" << i << "; ss += d * d; }\n";
-    }
-    // a non-finite solve (tanalisis.cpp:360-362) makes ss non-finite; so does an overflow of
-    // finite but absurd values -- both are left to the general kernel to classify exactly
-    o << g.ind << "const double err = sqrt(ss);\n"
-      << g.ind << "if (active) {\n"
-      << g.ind << "    if (pv || !(ss < 1.0e300)) { viol = true; active = false; }\n"
-      << g.ind << "    else {\n"
-      << g.ind << "        ++it;\n";
-    for (int i = 0; i < N; ++i) o << g.ind << "        X(" << i << ") = xn" << i << ";\n";
-    o << g.ind << "        if (err < " << lit(K.tran_tol) << ") active = false;\n"
-      << g.ind << "        else if (iter == " << (K.tran_max_iters - 1) << ") st |= ST_TRAN_NONCONV;\n"
-      << g.ind << "    }\n"
-      << g.ind << "}\n";
+    if (opt.dcMode) {
+        // ---- ConvController::update (reference src/dcanalysis.cpp:264-307) and the loop tail (:135-158)
+        std::ostringstream& o = g.out;
+        const double alpha = std::min(std::max(K.dc_alpha, K.dc_alpha_min), K.dc_alpha_max);     // :274
+        o << g.ind << "double ss = 0.0;\n";
+        for (int i = 0; i < N; ++i) {
+            o << g.ind << "const double xo" << i << " = X(" << i << ");\n"
+              << g.ind << "const double xn" << i << " = xo" << i << " + " << lit(alpha) << " * (xr" << i << " - xo" << i << ");\n"
+              << g.ind << "{ const double d = xn" << i << " - xo" << i << "; ss += d * d; }\n";
+        }
+        // a non-finite solve (the reference bumps gmin and retries, :135-138) or a failed pivot check
+        // sends the instance to the general kernel, which replays its operating point exactly
+        o << g.ind << "const double err = sqrt(ss);\n"
+          << g.ind << "if (active) {\n"
+          << g.ind << "    if (pv || !(ss < 1.0e300)) { viol = true; active = false; }\n"
+          << g.ind << "    else {\n"
+          << g.ind << "        ++itTotal;\n";
+        for (int i = 0; i < N; ++i) o << g.ind << "        X(" << i << ") = xn" << i << ";\n";
+        o << g.ind << "        double gnext;\n"
+          << g.ind << "        if (iter == 0 || !isfinite(prevErr)) gnext = gb;                                   // :280-282\n"
+          << g.ind << "        else if (err > __dmul_rn(prevErr, " << lit(K.slow_ratio) << ")) gnext = fmin(__dmul_rn(gminv, 2.0), " << lit(K.gmin_abs_max) << ");   // :285-288\n"
+          << g.ind << "        else if (err < __dmul_rn(prevErr, " << lit(K.fast_ratio) << ")) gnext = __dadd_rn(__dmul_rn(0.5, gminv), __dmul_rn(0.5, gb));   // :289-293\n"
+          << g.ind << "        else gnext = __dadd_rn(__dmul_rn(0.7, gminv), __dmul_rn(0.3, gb));               // :296\n"
+          << g.ind << "        gminv = gnext;\n"
+          << g.ind << "        prevErr = err;\n"
+          << g.ind << "        if (err < " << lit(K.dc_tol) << ") active = false;                                 // :150\n"
+          << g.ind << "        else if (iter == " << (K.dc_max_iters - 1) << ") st |= ST_DC_NONCONV;             // :153-158\n"
+          << g.ind << "    }\n"
+          << g.ind << "}\n";
+        src << g.out.str();
+        src << i2 << "}\n"      // NR loop
+            << "    }\n\n"     // ramp loop
+            << "    if (inb) {\n"
+            << "        if (viol) fallback[b] = 1;\n"
+            << "        else {\n"
+            << "            double* xo = xout + b;\n#pragma unroll 1\n"
+            << "            for (int i = 0; i < " << N << "; ++i, xo += SB) *xo = X(i);\n"
+            << "            iters[b] = itTotal;\n"
+            << "            status[b] = st;\n"
+            << "        }\n"
+            << "    }\n"
+            << "}\n\n";
+    } else {
+        // ---- damped update, norm in index order, convergence (tanalisis.cpp:360-376)
+        std::ostringstream& o = g.out;
+        o << g.ind << "double ss = 0.0;\n";
+        for (int i = 0; i < N; ++i) {
+            o << g.ind << "const double xo" << i << " = X(" << i << ");\n"
+              << g.ind << "const double xn" << i << " = xo" << i << " + " << lit(K.tran_alpha) << " * (xr" << i << " - xo" << i << ");\n"
+              << g.ind << "{ const double d = xn" << i << " - xo" << i << "; ss += d * d; }\n";
+        }
+        // a non-finite solve (tanalisis.cpp:360-362) makes ss non-finite; so does an overflow of
+        // finite but absurd values -- both are left to the general kernel to classify exactly
+        o << g.ind << "const double err = sqrt(ss);\n"
+          << g.ind << "if (active) {\n"
+          << g.ind << "    if (pv || !(ss < 1.0e300)) { viol = true; active = false; }\n"
+          << g.ind << "    else {\n"
+          << g.ind << "        ++it;\n";
+        for (int i = 0; i < N; ++i) o << g.ind << "        X(" << i << ") = xn" << i << ";\n";
+        o << g.ind << "        if (err < " << lit(K.tran_tol) << ") active = false;\n"
+          << g.ind << "        else if (iter == " << (K.tran_max_iters - 1) << ") st |= ST_TRAN_NONCONV;\n"
+          << g.ind << "    }\n"
+          << g.ind << "}\n";
 
-    src << g.out.str();
-    src << i2 << "}\n"      // NR loop
-        << i2 << "if (live && !viol) {\n"
-        << i2 << "    itTotal += it;\n"
-        << i2 << "    if (stepIters) stepIters[(s - 1) * SB + b] = it;\n"
-        << i2 << "    if (wave && !dead && (gstep % outStride) == 0) {\n"
-        << i2 << "        const long long row = gstep / outStride;\n"
-        << i2 << "        for (int q = 0; q < nProbe; ++q) wave[(row * nProbe + q) * SB + b] = X(probeEq[q]);\n"
-        << i2 << "    }\n"
-        << i2 << "    sdone = dead ? nSteps : s;\n"
-        << i2 << "}\n"
-        << "    }\n\n"
-        << "    if (inb) {\n"
-        << "        if (viol) fallback[b] = 1;               // xio holds the checkpoint of the step that failed\n"
-        << "        else {\n";
-    src << "            double* xo = xio + b;\n#pragma unroll 1\n"
-        << "            for (int i = 0; i < " << N << "; ++i, xo += SB) *xo = X(i);\n"
-        << "        }\n"
-        << "        iters[b] += itTotal;\n"
-        << "        status[b] |= st;\n"
-        << "        done[b] = (int)sdone;\n"
-        << "    }\n"
-        << "}\n\n";
+        src << g.out.str();
+        src << i2 << "}\n"      // NR loop
+            << i2 << "if (live && !viol) {\n"
+            << i2 << "    itTotal += it;\n"
+            << i2 << "    if (stepIters) stepIters[(s - 1) * SB + b] = it;\n"
+            << i2 << "    if (wave && !dead && (gstep % outStride) == 0) {\n"
+            << i2 << "        const long long row = gstep / outStride;\n"
+            << i2 << "        for (int q = 0; q < nProbe; ++q) wave[(row * nProbe + q) * SB + b] = X(probeEq[q]);\n"
+            << i2 << "    }\n"
+            << i2 << "    sdone = dead ? nSteps : s;\n"
+            << i2 << "}\n"
+            << "    }\n\n"
+            << "    if (inb) {\n"
+            << "        if (viol) fallback[b] = 1;               // xio holds the checkpoint of the step that failed\n"
+            << "        else {\n";
+        src << "            double* xo = xio + b;\n#pragma unroll 1\n"
+            << "            for (int i = 0; i < " << N << "; ++i, xo += SB) *xo = X(i);\n"
+            << "        }\n"
+            << "        iters[b] += itTotal;\n"
+            << "        status[b] |= st;\n"
+            << "        done[b] = (int)sdone;\n"
+            << "    }\n"
+            << "}\n\n";
+
+    }
 
     if (statsOut) *statsOut = g.st;
     return ldsNext;
@@ -827,7 +940,7 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "//   csim_tran_sched_kernel_rich  every finished U-row value parked in LDS (tuning aid: measured\n"
         << "//                                slower -- ds traffic costs more than the spills it removes)\n"
         << "#include <hip/hip_runtime.h>\n#include <stdint.h>\n\n"
-        << "#define ST_TRAN_NONFINITE 0x0001u\n#define ST_TRAN_NONCONV 0x0002u\n\n"
+        << "#define ST_TRAN_NONFINITE 0x0001u\n#define ST_TRAN_NONCONV 0x0002u\n#define ST_DC_NONCONV 0x0008u\n\n"
         << "#define Q(k) lds[(k) * 64 + lane]\n#define X(i) Q(i)\n#define S(j) Q(" << N << " + (j))\n\n"
         << "// Newton-refined reciprocal (v_rcp_f64 + 2 FMA pairs, ~1 ulp) for the pivots\n"
         << "__device__ __forceinline__ double clamp01_cg(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }\n"
@@ -871,6 +984,16 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         }
     }
 
+    // DC operating point with its own recorded schedules (Newton circuits only: a linear circuit's
+    // DC is one solve, left to the general kernel)
+    int ldsDc = -1;
+    if (!set.dcAlts.empty() && ir.has_nonlinear) {
+        VariantOptions dcOpt{"csim_dc_sched_kernel", false, false, leanBudget > 0 ? leanBudget : 0};
+        dcOpt.dcMode = true;
+        ldsDc = emitVariant(dcOpt, nullptr);
+    }
+    const bool haveDc = ldsDc >= 0;
+
     char hbuf[32];
     std::snprintf(hbuf, sizeof hbuf, "0x%016llxull", static_cast<unsigned long long>(hash));
     char tbuf[32];
@@ -886,7 +1009,25 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     for (std::size_t a = 0; a < set.alts.size(); ++a)
         for (int k = 0; k < N; ++k) src << (a + k ? ", " : "") << set.alts[a].pivotPos[static_cast<std::size_t>(k)];
     src << "};\n    *nAlts = " << set.alts.size() << ";\n    *n = " << N << ";\n    return table;\n}\n"
-        << "// variant: 0/1 = lean (measured fastest at every batch size: park-budget sweep in DESIGN.md),\n"
+        << "// DC operating point: recorded alternatives and launcher (n_alts == 0: no DC kernel in this library)\n"
+        << "extern \"C\" const int* csim_sched_dc_alts(int* nAlts, int* n)\n{\n    static const int table[] = {";
+    if (haveDc) {
+        for (std::size_t a = 0; a < set.dcAlts.size(); ++a)
+            for (int k = 0; k < N; ++k) src << (a + k ? ", " : "") << set.dcAlts[a].pivotPos[static_cast<std::size_t>(k)];
+    } else {
+        src << "0";
+    }
+    src << "};\n    *nAlts = " << (haveDc ? set.dcAlts.size() : 0) << ";\n    *n = " << N << ";\n    return table;\n}\n"
+        << "extern \"C\" int csim_sched_dc_launch(const double* params, int B, double* xout, int* iters, unsigned* status,\n"
+        << "                                    unsigned char* fallback, void* stream)\n{\n";
+    if (haveDc)
+        src << "    if (B <= 0) return 0;\n"
+            << "    hipLaunchKernelGGL(csim_dc_sched_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream,\n"
+            << "                       params, B, xout, iters, status, fallback);\n"
+            << "    return (int)hipGetLastError();\n}\n";
+    else
+        src << "    (void)params; (void)B; (void)xout; (void)iters; (void)status; (void)fallback; (void)stream;\n    return -1;\n}\n";
+    src << "// variant: 0/1 = lean (measured fastest at every batch size: park-budget sweep in DESIGN.md),\n"
         << "//          2 = rich (tuning aid), 10+k = sweep kernels when generated with CSIM_CG_SWEEP\n"
         << "extern \"C\" int csim_sched_launch(const double* params, int B, double dt, long long stepFirst, long long nSteps,\n"
         << "                                 const int* probeEq, int nProbe, int outStride, double* wave, double* xio,\n"

@@ -50,8 +50,10 @@ struct PivotSchedule {
 // sequences).  The generated kernel carries one solve body per alternative and tries them in
 // order, per Newton iteration, for the lanes whose pivot checks failed so far.
 struct ScheduleSet {
-    std::vector<PivotSchedule> alts;       // most frequent first
-    // one schedule per line (or ';'-separated); '#' starts a comment; "-" = no swaps
+    std::vector<PivotSchedule> alts;       // transient; most frequent first
+    std::vector<PivotSchedule> dcAlts;     // DC operating point (lines prefixed "dc"); may be empty
+    // one schedule per line (or ';'-separated); '#' starts a comment; "-" = no swaps;
+    // "dc <schedule>" = a schedule of the DC Newton solve
     static bool parse(const std::string& text, int N, ScheduleSet& out);
     std::string str() const;
 };

@@ -6,6 +6,7 @@
 #include <unistd.h>
 
 #include <cmath>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -135,6 +136,14 @@ void adoptScheduleTable(csim_engine* eng, void* lib)
     AltsFn fn = reinterpret_cast<AltsFn>(dlsym(lib, "csim_sched_alts"));
     eng->nKnownAlts = 0;
     if (eng->dKnownAlts) { (void)hipFree(eng->dKnownAlts); eng->dKnownAlts = nullptr; }
+    // DC operating-point kernel, present when the library was generated with "dc" schedules
+    eng->schedDcLaunch = nullptr;
+    if (AltsFn dcAlts = reinterpret_cast<AltsFn>(dlsym(lib, "csim_sched_dc_alts"))) {
+        int nDc = 0, nn = 0;
+        (void)dcAlts(&nDc, &nn);
+        if (nDc > 0 && nn == eng->plan.N)
+            eng->schedDcLaunch = reinterpret_cast<csim_engine::SchedDcLaunchFn>(dlsym(lib, "csim_sched_dc_launch"));
+    }
     if (!fn) return;
     int nAlts = 0, n = 0;
     const int* table = fn(&nAlts, &n);
@@ -260,6 +269,21 @@ int csim_mc_params_dev(csim_engine* eng, uint64_t seed, double sigma, int64_t b_
     return CSIM_OK;
 }
 
+// per-instance fallback mask and progress counters of the scheduled kernels
+static int ensureFallbackBuffers(csim_engine* eng, int32_t B)
+{
+    if (eng->fallbackCap >= B) return CSIM_OK;
+    if (eng->dFallback) HIPCHK(hipFree(eng->dFallback));
+    if (eng->dDone) HIPCHK(hipFree(eng->dDone));
+    eng->dFallback = nullptr;
+    eng->dDone = nullptr;
+    eng->fallbackCap = 0;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dFallback), (size_t)B));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dDone), sizeof(int32_t) * (size_t)B));
+    eng->fallbackCap = B;
+    return CSIM_OK;
+}
+
 int csim_dc_batch_dev(csim_engine* eng, const double* d_params, int32_t B, double* d_x,
                       int32_t* d_iters, uint32_t* d_status, void* stream)
 {
@@ -275,7 +299,21 @@ int csim_dc_batch_dev(csim_engine* eng, const double* d_params, int32_t B, doubl
         HIPCHK(csim::launchDcBig(eng->gpDc, d_params, B, eng->dBigScratch, d_x, d_iters, d_status, static_cast<hipStream_t>(stream)));
         return CSIM_OK;
     }
-    HIPCHK(csim::launchDcGeneral(eng->gpDc, d_params, B, d_x, d_iters, d_status, static_cast<hipStream_t>(stream)));
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    if (eng->schedDcLaunch && eng->kernelChoice != 1) {
+        // lane-per-instance kernel on the recorded DC pivot sequences; an instance that fails a pivot
+        // check (or meets a non-finite solve) is replayed from x = 0 by the general kernel
+        const int rc = ensureFallbackBuffers(eng, B);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(eng->dFallback, 0, (size_t)B, hs));
+        if (eng->schedDcLaunch(d_params, B, d_x, d_iters, d_status, eng->dFallback, stream) != 0) {
+            setError("scheduled DC kernel launch failed");
+            return CSIM_ERR_HIP;
+        }
+        HIPCHK(csim::launchDcGeneral(eng->gpDc, d_params, B, d_x, d_iters, d_status, hs, eng->dFallback));
+        return CSIM_OK;
+    }
+    HIPCHK(csim::launchDcGeneral(eng->gpDc, d_params, B, d_x, d_iters, d_status, hs));
     return CSIM_OK;
 }
 
@@ -324,14 +362,9 @@ int csim_tran_batch_dev(csim_engine* eng, const double* d_params, int32_t B, dou
     // step and records per-instance progress in dDone.  The general kernel then advances the
     // unfinished instances by a couple of steps with run-time pivoting and hands them back.
     // Blocks/lanes with nothing left exit at once, so the extra launches cost microseconds.
-    if (eng->fallbackCap < B) {
-        if (eng->dFallback) HIPCHK(hipFree(eng->dFallback));
-        if (eng->dDone) HIPCHK(hipFree(eng->dDone));
-        eng->dFallback = nullptr;
-        eng->dDone = nullptr;
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dFallback), (size_t)B));
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dDone), sizeof(int32_t) * (size_t)B));
-        eng->fallbackCap = B;
+    {
+        const int rc = ensureFallbackBuffers(eng, B);
+        if (rc) return rc;
     }
     HIPCHK(hipMemsetAsync(eng->dFallback, 0, (size_t)B, hs));
     HIPCHK(hipMemsetAsync(eng->dDone, 0, sizeof(int32_t) * (size_t)B, hs));
@@ -512,6 +545,29 @@ int csim_lu_solve_batch(int32_t device, int32_t n, int32_t B, const double* A, c
     return CSIM_OK;
 }
 
+// planner log (device_common.hpp PIVLOG_*) -> the distinct sequences, most frequent first
+static void decodePivotLog(const std::vector<int32_t>& log, int N, int32_t max_alts, int32_t* pivot_pos,
+                           int64_t* counts, int32_t* n_alts, int64_t* n_other)
+{
+    std::vector<int> order;
+    for (int s2 = 0; s2 < log[0]; ++s2) order.push_back(s2);
+    auto cnt = [&](int s2) { return log[(size_t)(3 + s2 * (N + 1) + N)]; };
+    for (size_t i = 0; i < order.size(); ++i)
+        for (size_t j = i + 1; j < order.size(); ++j)
+            if (cnt(order[j]) > cnt(order[i])) std::swap(order[i], order[j]);
+    int64_t other = log[2];
+    int out = 0;
+    for (int s2 : order) {
+        if (out < max_alts) {
+            for (int k = 0; k < N; ++k) pivot_pos[(size_t)out * N + k] = log[(size_t)(3 + s2 * (N + 1) + k)];
+            if (counts) counts[out] = cnt(s2);
+            ++out;
+        } else other += cnt(s2);
+    }
+    *n_alts = out;
+    if (n_other) *n_other = other;
+}
+
 int csim_record_pivot_schedules(csim_engine* eng, const double* d_params, int32_t B, int32_t instance,
                                 double tstep, int64_t n_steps, int32_t max_alts, int32_t* pivot_pos,
                                 int64_t* counts, int32_t* n_alts, int64_t* n_other)
@@ -554,24 +610,38 @@ int csim_record_pivot_schedules(csim_engine* eng, const double* d_params, int32_
     HIPCHK(hipDeviceSynchronize());
     std::vector<int32_t> log((size_t)logInts);
     HIPCHK(hipMemcpy(log.data(), dLog.p, sizeof(int32_t) * log.size(), hipMemcpyDeviceToHost));
-    // most frequent first
-    std::vector<int> order;
-    for (int s2 = 0; s2 < log[0]; ++s2) order.push_back(s2);
-    auto cnt = [&](int s2) { return log[(size_t)(3 + s2 * (N + 1) + N)]; };
-    for (size_t i = 0; i < order.size(); ++i)
-        for (size_t j = i + 1; j < order.size(); ++j)
-            if (cnt(order[j]) > cnt(order[i])) std::swap(order[i], order[j]);
-    int64_t other = log[2];
-    int out = 0;
-    for (int s2 : order) {
-        if (out < max_alts) {
-            for (int k = 0; k < N; ++k) pivot_pos[(size_t)out * N + k] = log[(size_t)(3 + s2 * (N + 1) + k)];
-            if (counts) counts[out] = cnt(s2);
-            ++out;
-        } else other += cnt(s2);
+    decodePivotLog(log, N, max_alts, pivot_pos, counts, n_alts, n_other);
+    return CSIM_OK;
+}
+
+int csim_record_dc_pivot_schedules(csim_engine* eng, const double* d_params, int32_t B, int32_t instance,
+                                   int32_t max_alts, int32_t* pivot_pos, int64_t* counts, int32_t* n_alts,
+                                   int64_t* n_other)
+{
+    if (!eng || !d_params || !pivot_pos || !n_alts || B <= 0 || instance < 0 || instance >= B || max_alts <= 0) {
+        setError("csim_record_dc_pivot_schedules: bad argument");
+        return CSIM_ERR_ARG;
     }
-    *n_alts = out;
-    if (n_other) *n_other = other;
+    if (eng->big) { setError("the DC planner covers circuits of up to 63 unknowns"); return CSIM_ERR_UNSUPPORTED; }
+    HIPCHK(hipSetDevice(eng->device));
+    const int N = eng->plan.N;
+    const int logInts = csim::pivlog_ints(N);
+    DevBuf dX, dIt32, dSt, dLog, dOnly;
+    HIPCHK(dX.alloc(sizeof(double) * (size_t)N * B));
+    HIPCHK(dIt32.alloc(sizeof(int32_t) * (size_t)B));
+    HIPCHK(dSt.alloc(sizeof(uint32_t) * (size_t)B));
+    HIPCHK(dLog.alloc(sizeof(int32_t) * (size_t)logInts));
+    HIPCHK(dOnly.alloc((size_t)B));
+    HIPCHK(hipMemset(dLog.p, 0, sizeof(int32_t) * (size_t)logInts));
+    HIPCHK(hipMemset(dOnly.p, 0, (size_t)B));
+    const unsigned char one = 1;
+    HIPCHK(hipMemcpy(dOnly.as<unsigned char>() + instance, &one, 1, hipMemcpyHostToDevice));
+    HIPCHK(csim::launchDcGeneral(eng->gpDc, d_params, B, dX.as<double>(), dIt32.as<int32_t>(), dSt.as<uint32_t>(), nullptr,
+                                 dOnly.as<uint8_t>(), dLog.as<int32_t>(), instance));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<int32_t> log((size_t)logInts);
+    HIPCHK(hipMemcpy(log.data(), dLog.p, sizeof(int32_t) * log.size(), hipMemcpyDeviceToHost));
+    decodePivotLog(log, N, max_alts, pivot_pos, counts, n_alts, n_other);
     return CSIM_OK;
 }
 
@@ -613,6 +683,29 @@ int csim_engine_jit_scheduled(csim_engine* eng, const double* d_params, int32_t 
         csim::PivotSchedule one = csim::PivotSchedule::identity(N);
         for (int k = 0; k < N; ++k) one.pivotPos[(size_t)k] = pos[(size_t)a * N + k];
         sch.alts.push_back(one);
+    }
+    // The DC operating point of Newton circuits gets its own schedules (planned on the same instance),
+    // but only when a few sequences cover that instance's whole ramp: a circuit that walks through many
+    // (buffer.sp: 10) would fail its checks in most instances and pay for both kernels.
+    // CSIM_JIT_DC_ALTS = limit (default 4, at most 8); CSIM_JIT_DC_FORCE=1 keeps a partial cover (tests).
+    if (ir->has_nonlinear && !eng->big) {
+        const int planMax = 8;
+        int limit = 4;
+        if (const char* v = std::getenv("CSIM_JIT_DC_ALTS")) limit = std::max(0, std::min(planMax, std::atoi(v)));
+        const bool force = std::getenv("CSIM_JIT_DC_FORCE") != nullptr;
+        std::vector<int32_t> dpos((size_t)planMax * N);
+        int32_t nDc = 0;
+        int64_t dcOther = 0;
+        rc = csim_record_dc_pivot_schedules(eng, d_params, B, 0, planMax, dpos.data(), nullptr, &nDc, &dcOther);
+        if (rc) return rc;
+        const bool covered = nDc > 0 && nDc <= limit && dcOther == 0;
+        if (covered || (force && nDc > 0)) {
+            for (int a = 0; a < nDc && a < std::max(limit, 1); ++a) {
+                csim::PivotSchedule one = csim::PivotSchedule::identity(N);
+                for (int k = 0; k < N; ++k) one.pivotPos[(size_t)k] = dpos[(size_t)a * N + k];
+                sch.dcAlts.push_back(one);
+            }
+        }
     }
 
     const unsigned long long topo = csim::scheduleHash(*ir, csim::PivotSchedule::identity(N));

@@ -30,8 +30,11 @@ struct csim_engine {
     // circuit-specialised transient kernel (side library libcsim_sched_<topology>.so)
     typedef int (*SchedLaunchFn)(const double*, int, double, long long, long long, const int*, int, int,
                                  double*, double*, long long*, unsigned*, int*, unsigned char*, int*, void*, int);
+    // DC operating point of the same library (nullptr: the library carries no DC schedule)
+    typedef int (*SchedDcLaunchFn)(const double*, int, double*, int*, unsigned*, unsigned char*, void*);
     void* schedLib = nullptr;
     SchedLaunchFn schedLaunch = nullptr;
+    SchedDcLaunchFn schedDcLaunch = nullptr;
     std::string schedInfo;
     int32_t* dKnownAlts = nullptr;         // [nKnownAlts][N] pivot sequences the loaded kernel carries
     int nKnownAlts = 0;

@@ -10,7 +10,8 @@ namespace csim {
 
 // wave-per-instance kernels (kernels_general.hip)
 hipError_t launchDcGeneral(const GenPlan& pl, const double* dParams, int B, double* dX,
-                           int32_t* dIters, uint32_t* dStatus, hipStream_t stream);
+                           int32_t* dIters, uint32_t* dStatus, hipStream_t stream, const uint8_t* dOnly = nullptr,
+                           int32_t* dPivLog = nullptr, int pivInstance = 0);
 hipError_t launchTranGeneral(const GenPlan& pl, const double* dParams, int B, double dt,
                              long long stepFirst, long long nSteps, const int32_t* dProbeEq, int nProbe,
                              int outStride, double* dWave, double* dX, long long* dIters,

@@ -41,11 +41,14 @@ __device__ __forceinline__ bool wave_all_finite(double v, int N, int lane)
 // ------------------------------------------------------------------ DC (K2)
 __global__ void __launch_bounds__(64)
 k_dc_general(GenPlan pl, const double* __restrict__ params, int B,
-             double* __restrict__ xout, int32_t* __restrict__ iters, uint32_t* __restrict__ status)
+             double* __restrict__ xout, int32_t* __restrict__ iters, uint32_t* __restrict__ status,
+             const uint8_t* __restrict__ only, int32_t* __restrict__ pivLog, int pivInstance)
 {
     extern __shared__ double sm[];
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
+    if (only && !only[b]) return;           // fallback / planner launches touch the flagged instances only
+    int32_t* myPivLog = (pivLog && b == pivInstance) ? pivLog : nullptr;
     const int N = pl.N, LD = pl.LD;
     const LdsLayout L = ldsLayout(N, LD, pl.nTerms, pl.P);
     double* Gm = sm + L.G;
@@ -86,7 +89,7 @@ k_dc_general(GenPlan pl, const double* __restrict__ params, int B,
                 if (lane == 0) T[pl.termGmin] = gmin;
                 wave_sync();
                 assemble(pl, T, Gm, lane);
-                const double xr = lu_solve_wave(Gm, N, LD, K.lu_eps, lane, st);   // :134
+                const double xr = lu_solve_wave(Gm, N, LD, K.lu_eps, lane, st, myPivLog, nullptr);   // :134
                 ++itTotal;
                 if (!wave_all_finite(xr, N, lane)) {                    // :135-138
                     gmin = fmin(gmin * K.gmin_nonfinite_mul, K.gmin_nonfinite_cap);
@@ -117,7 +120,7 @@ k_dc_general(GenPlan pl, const double* __restrict__ params, int B,
     if (lane < N) xout[(int64_t)lane * B + b] = xs[lane];
     if (lane == 0) {
         iters[b] = itTotal;
-        status[b] = st;
+        status[b] = (only && !pivLog) ? (st | CSIM_ST_SCHED_FALLBACK_DC) : st;
     }
 }
 
@@ -270,11 +273,13 @@ hipError_t launchLuFactor(int n, int B, const double* dA, double* dLU, int32_t* 
 }
 
 hipError_t launchDcGeneral(const GenPlan& pl, const double* dParams, int B, double* dX,
-                           int32_t* dIters, uint32_t* dStatus, hipStream_t stream)
+                           int32_t* dIters, uint32_t* dStatus, hipStream_t stream, const uint8_t* dOnly,
+                           int32_t* dPivLog, int pivInstance)
 {
     const LdsLayout L = ldsLayout(pl.N, pl.LD, pl.nTerms, pl.P);
     const size_t lds = sizeof(double) * (size_t)L.total;
-    hipLaunchKernelGGL(k_dc_general, dim3(B), dim3(64), lds, stream, pl, dParams, B, dX, dIters, dStatus);
+    hipLaunchKernelGGL(k_dc_general, dim3(B), dim3(64), lds, stream, pl, dParams, B, dX, dIters, dStatus, dOnly,
+                       dPivLog, pivInstance);
     return hipGetLastError();
 }
 

@@ -40,6 +40,12 @@ class Netlist:
         self.mc_kinds = np.zeros(self.n_params, dtype=np.int32)
         capi.check(L.csim_netlist_mc_kinds(self._h, self.mc_kinds.ctypes.data))
 
+    @property
+    def has_nonlinear(self):
+        """any MOSFET -> Newton DC (csim_ir.has_nonlinear)"""
+        ir = capi.lib().csim_netlist_ir(self._h)
+        return bool(C.cast(ir, C.POINTER(C.c_int32))[5])
+
     def _n_params(self):
         # csim_ir: int32 n_unknowns, n_node_eq, n_branch_eq, n_elems, n_params, ...
         ir = capi.lib().csim_netlist_ir(self._h)
@@ -251,6 +257,20 @@ class Engine:
         capi.check(capi.lib().csim_record_pivot_schedules(self._h, params.data_ptr(), params.shape[1], instance,
                                                           float(tstep), int(n_steps), max_alts, pos.ctypes.data,
                                                           counts.ctypes.data, C.byref(n_alts), C.byref(other)))
+        out = []
+        for a in range(n_alts.value):
+            sched = ",".join("%d:%d" % (k, p) for k, p in enumerate(pos[a]) if p != k) or "-"
+            out.append((sched, int(counts[a])))
+        return out, other.value
+
+    def record_dc_pivot_schedules(self, params, instance=0, max_alts=8):
+        """Planner on the DC operating point of one instance: ([(schedule string, count), ...], n_other)."""
+        pos = np.zeros((max_alts, self.N), dtype=np.int32)
+        counts = np.zeros(max_alts, dtype=np.int64)
+        n_alts, other = C.c_int32(), C.c_int64()
+        capi.check(capi.lib().csim_record_dc_pivot_schedules(self._h, params.data_ptr(), params.shape[1], instance,
+                                                             max_alts, pos.ctypes.data, counts.ctypes.data,
+                                                             C.byref(n_alts), C.byref(other)))
         out = []
         for a in range(n_alts.value):
             sched = ",".join("%d:%d" % (k, p) for k, p in enumerate(pos[a]) if p != k) or "-"

@@ -197,6 +197,12 @@ int  csim_record_pivot_schedule(csim_engine* eng, const double* d_params /*[P][B
 int  csim_record_pivot_schedules(csim_engine* eng, const double* d_params /*[P][B]*/, int32_t B,
                                  int32_t instance, double tstep, int64_t n_steps, int32_t max_alts,
                                  int32_t* pivot_pos, int64_t* counts, int32_t* n_alts, int64_t* n_other);
+/* The same planner on the DC operating point of instance `instance` (source ramp + adaptive
+ * gmin, reference src/dcanalysis.cpp:95-163): its distinct pivot sequences, most frequent first
+ * ("dc" lines of a schedule file).  Circuits of up to 63 unknowns.                           */
+int  csim_record_dc_pivot_schedules(csim_engine* eng, const double* d_params /*[P][B]*/, int32_t B,
+                                    int32_t instance, int32_t max_alts, int32_t* pivot_pos,
+                                    int64_t* counts, int32_t* n_alts, int64_t* n_other);
 
 #ifdef __cplusplus
 }

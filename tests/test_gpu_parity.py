@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-9
 FALLBACK = 0x20          # CSIM_ST_SCHED_FALLBACK: informational (instance was re-run by the general kernel)
-NOFB = 0xFFFFFFDF        # mask that drops it
+FALLBACK_DC = 0x80       # CSIM_ST_SCHED_FALLBACK_DC: the same for the DC operating point
+NOFB = 0xFFFFFF5F        # mask that drops both
 
 
 @pytest.fixture(scope="module")
@@ -468,10 +469,14 @@ def test_committed_schedules_match_the_planner(engines, torch_mod):
 
     nl, eng = engines["dbmixer"]
     params = eng.mc_params(12345, 0.05, 0, 4)
-    assert len(committed("dbmixer")) == 1
+    tran_lines = [l for l in committed("dbmixer") if not l.startswith("dc")]
+    dc_lines = [l[2:].strip() for l in committed("dbmixer") if l.startswith("dc")]
+    assert len(tran_lines) == 1 and len(dc_lines) == 1
     for b in range(4):
         sched, nlu, ndiff = eng.record_pivot_schedule(params, b, None, 1500)
-        assert sched == committed("dbmixer")[0] and ndiff == 0 and nlu > 10000
+        assert sched == tran_lines[0] and ndiff == 0 and nlu > 10000
+        dcs, other = eng.record_dc_pivot_schedules(params, b)            # the DC ramp keeps one sequence too
+        assert [a for a, _ in dcs] == dc_lines and other == 0 and 400 < dcs[0][1] < 520
     nl, eng = engines["buffer"]
     params = eng.mc_params(12345, 0.05, 0, 2)
     sched, nlu, ndiff = eng.record_pivot_schedule(params, 0, 3e-11, 3000)
@@ -775,3 +780,68 @@ def test_pulse_pwl_sources_general_and_scheduled(torch_mod, tmp_path, monkeypatc
     o = orc.tran(nl.ir_ptr, nl.n_unknowns, nl.nominal_params, 0, nl.tstep, nl.tstop)
     assert it[0] == o["iters"] and st[0] & NOFB == 0
     assert rel_err(wave[0], o["rows"][:, 1:], nl.n_node_eq).max() < TOL
+
+
+# --------------------------------------------- scheduled DC operating-point kernel
+
+def test_scheduled_dc_kernel_equals_general_and_oracle(engines, torch_mod):
+    """The generated lane-per-instance DC kernel (source ramp + ConvController on the recorded "dc"
+    pivot sequences) against the general kernel on the whole batch and the oracle on a sample."""
+    import time
+    torch = torch_mod
+    nl, eng = engines["dbmixer"]
+    B = 4096
+    params = eng.mc_params(12345, 0.05, 0, B)
+    eng.set_kernel("general")
+    x_g, it_g, st_g = eng.dc(params)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x_g, it_g, st_g = eng.dc(params)
+    torch.cuda.synchronize()
+    t_general = time.perf_counter() - t0
+    eng.set_kernel("auto")
+    x_s, it_s, st_s = eng.dc(params)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x_s, it_s, st_s = eng.dc(params)
+    torch.cuda.synchronize()
+    t_sched = time.perf_counter() - t0
+    print("DC B=%d: general %.2f ms, scheduled %.2f ms" % (B, 1e3 * t_general, 1e3 * t_sched))
+    xg, xs = x_g.cpu().numpy(), x_s.cpu().numpy()
+    stg, sts = st_g.cpu().numpy().astype(np.uint32), st_s.cpu().numpy().astype(np.uint32)
+    assert np.array_equal(it_g.cpu().numpy(), it_s.cpu().numpy())
+    assert np.array_equal(stg, sts & NOFB)
+    assert ((sts & FALLBACK_DC) != 0).sum() <= B // 100       # the scheduled kernel really produced the results
+    assert rel_err(xs.T, xg.T, nl.n_node_eq).max() < TOL
+    assert t_sched < t_general                                   # and it is the faster path
+    ph = params.cpu().numpy()
+    for b in (0, 1, 777, 4095):
+        xo, ito, sto = _orc().dc(nl.ir_ptr, nl.n_unknowns, ph, b)
+        assert it_s[b].item() == ito and (sts[b] & NOFB) == sto
+        assert rel_err(xs[:, b], xo, nl.n_node_eq).max() < TOL
+
+
+def test_scheduled_dc_violators_are_replayed_by_the_general_kernel(torch_mod, tmp_path, monkeypatch):
+    """A circuit whose DC ramp walks through many pivot sequences (buffer.sp: 10 in the nominal
+    instance, 15 over a Monte-Carlo batch).  By default the JIT gives such a circuit no DC kernel;
+    forced to keep a partial cover, instances violate and must come back from the general kernel
+    with identical results."""
+    from circuitsimulator_amd import Engine, Netlist
+    monkeypatch.setenv("CSIM_JIT_DIR", str(tmp_path / "jit"))
+    monkeypatch.setenv("CSIM_JIT_DC_FORCE", "1")
+    nl = Netlist.from_file(netlist_path("buffer.sp"))
+    eng = Engine(nl, 0)
+    B = 256
+    params = eng.mc_params(7, 0.05, 0, B)
+    eng.set_kernel("general")
+    x_g, it_g, st_g = eng.dc(params)
+    eng.set_kernel("auto")
+    eng.jit_scheduled(params, plan_steps=300)
+    x_s, it_s, st_s = eng.dc(params)
+    sts = st_s.cpu().numpy().astype(np.uint32)
+    nfb = int(((sts & FALLBACK_DC) != 0).sum())
+    print("buffer DC: %d of %d instances replayed by the general kernel" % (nfb, B))
+    assert 0 < nfb <= B
+    assert np.array_equal(it_g.cpu().numpy(), it_s.cpu().numpy())
+    assert np.array_equal(st_g.cpu().numpy().astype(np.uint32), sts & NOFB)
+    assert rel_err(x_s.cpu().numpy().T, x_g.cpu().numpy().T, nl.n_node_eq).max() < TOL

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Record the transient pivot schedule of a netlist with the general kernel (needs a GPU).
+"""Record the transient (and DC) pivot schedules of a netlist with the general kernel (needs a GPU).
 
     python tools/record_schedule.py tests/golden/dbmixer.sp [--steps 2000] [--tstep 1e-13] [--mc 16]
 
@@ -26,8 +26,14 @@ def main():
     nl = Netlist.from_file(a.netlist)
     eng = Engine(nl, 0)
     params = eng.mc_params(12345, 0.05, 0, max(1, a.mc))
-    total = {}
+    total, total_dc = {}, {}
     for b in range(max(1, a.mc)):
+        if nl.has_nonlinear and nl.n_unknowns <= 63:
+            dcs, dother = eng.record_dc_pivot_schedules(params, b)
+            print("instance %3d DC: %s%s" % (b, "  ".join("[%s] x%d" % sc for sc in dcs),
+                                             ("  other/failed x%d" % dother) if dother else ""))
+            for sched, n in dcs:
+                total_dc[sched] = total_dc.get(sched, 0) + n
         alts, other = eng.record_pivot_schedules(params, b, a.tstep, a.steps)
         print("instance %3d: %s%s" % (b, "  ".join("[%s] x%d" % sc for sc in alts),
                                       ("  other/failed x%d" % other) if other else ""))
@@ -36,6 +42,10 @@ def main():
     print("\n# schedule file body (most frequent first; one alternative per line):")
     for sched, n in sorted(total.items(), key=lambda kv: -kv[1]):
         print("%s    # %d factorisations" % (sched, n))
+    if total_dc:
+        print("# DC operating point (worth listing when a handful of sequences covers every instance):")
+        for sched, n in sorted(total_dc.items(), key=lambda kv: -kv[1]):
+            print("dc %s    # %d factorisations" % (sched, n))
 
 
 if __name__ == "__main__":

@@ -42,7 +42,7 @@ def main():
     total = int(iters.sum().item())
     rec = {"batch": B, "steps": a.steps, "kernel": eng.tran_kernel, "dc_s": t_dc, "tran_s": t_tr,
            "nr_iters": total, "nr_iters_instance0": int(iters[0]), "rate": total / t_tr,
-           "flagged": int((st & 0x27).ne(0).sum().item()),
+           "flagged": int((st & 0xA7).ne(0).sum().item()),
            "V102_mean_std": [float(v[0].mean()), float(v[0].std())],
            "V103_mean_std": [float(v[1].mean()), float(v[1].std())],
            "V102_V103_nominal": [float(v[0][0]), float(v[1][0])]}
