@@ -529,7 +529,7 @@ int csim_lu_solve_batch(int32_t device, int32_t n, int32_t B, const double* A, c
         return CSIM_ERR_NO_DEVICE;
     }
     if (n == 0 || B == 0) return CSIM_OK;              // solver.hpp:86: empty system -> empty vector
-    if (n > 63) { setError("csim_lu_solve_batch covers n <= 63"); return CSIM_ERR_UNSUPPORTED; }
+    if (n > 1024) { setError("csim_lu_solve_batch covers n <= 1024"); return CSIM_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(device));
     DevBuf dA, dB, dX, dF;
     HIPCHK(dA.alloc(sizeof(double) * (size_t)n * n * B));
@@ -538,7 +538,10 @@ int csim_lu_solve_batch(int32_t device, int32_t n, int32_t B, const double* A, c
     HIPCHK(dF.alloc(sizeof(uint32_t) * (size_t)B));
     HIPCHK(hipMemcpy(dA.p, A, sizeof(double) * (size_t)n * n * B, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dB.p, b, sizeof(double) * (size_t)n * B, hipMemcpyHostToDevice));
-    HIPCHK(csim::launchLuSolve(n, B, dA.as<double>(), dB.as<double>(), dX.as<double>(), dF.as<uint32_t>(), 1e-15, nullptr));
+    if (n > 63)      // dense systems beyond the LDS-resident kernel: in place in global memory (kernels_dense.hip)
+        HIPCHK(csim::launchLuSolveDense(n, B, dA.as<double>(), dB.as<double>(), dX.as<double>(), dF.as<uint32_t>(), 1e-15, nullptr));
+    else
+        HIPCHK(csim::launchLuSolve(n, B, dA.as<double>(), dB.as<double>(), dX.as<double>(), dF.as<uint32_t>(), 1e-15, nullptr));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(x, dX.p, sizeof(double) * (size_t)n * B, hipMemcpyDeviceToHost));
     if (flags) HIPCHK(hipMemcpy(flags, dF.p, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost));
@@ -761,15 +764,20 @@ int csim_lu_decompose_batch(int32_t device, int32_t n, int32_t B, const double* 
         return CSIM_ERR_NO_DEVICE;
     }
     if (n == 0 || B == 0) return CSIM_OK;
-    if (n > 63) { setError("csim_lu_decompose_batch covers n <= 63"); return CSIM_ERR_UNSUPPORTED; }
+    if (n > 1024) { setError("csim_lu_decompose_batch covers n <= 1024"); return CSIM_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(device));
     DevBuf dA, dLU, dP, dF;
-    HIPCHK(dA.alloc(sizeof(double) * (size_t)n * n * B));
     HIPCHK(dLU.alloc(sizeof(double) * (size_t)n * n * B));
     HIPCHK(dP.alloc(sizeof(int32_t) * (size_t)n * B));
     HIPCHK(dF.alloc(sizeof(uint32_t) * (size_t)B));
-    HIPCHK(hipMemcpy(dA.p, A, sizeof(double) * (size_t)n * n * B, hipMemcpyHostToDevice));
-    HIPCHK(csim::launchLuFactor(n, B, dA.as<double>(), dLU.as<double>(), dP.as<int32_t>(), dF.as<uint32_t>(), 1e-15, nullptr));
+    if (n > 63) {    // in place on the copy (kernels_dense.hip)
+        HIPCHK(hipMemcpy(dLU.p, A, sizeof(double) * (size_t)n * n * B, hipMemcpyHostToDevice));
+        HIPCHK(csim::launchLuFactorDense(n, B, dLU.as<double>(), dP.as<int32_t>(), dF.as<uint32_t>(), 1e-15, nullptr));
+    } else {
+        HIPCHK(dA.alloc(sizeof(double) * (size_t)n * n * B));
+        HIPCHK(hipMemcpy(dA.p, A, sizeof(double) * (size_t)n * n * B, hipMemcpyHostToDevice));
+        HIPCHK(csim::launchLuFactor(n, B, dA.as<double>(), dLU.as<double>(), dP.as<int32_t>(), dF.as<uint32_t>(), 1e-15, nullptr));
+    }
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(LU, dLU.p, sizeof(double) * (size_t)n * n * B, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(perm, dP.p, sizeof(int32_t) * (size_t)n * B, hipMemcpyDeviceToHost));

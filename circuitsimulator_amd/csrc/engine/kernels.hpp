@@ -25,6 +25,12 @@ hipError_t launchLuFactor(int n, int B, const double* dA, double* dLU, int32_t* 
                           double eps, hipStream_t stream);
 size_t generalLdsBytes(const GenPlan& pl);
 
+// dense stand-alone LU for 64 <= n <= 1024, one workgroup per system, in place (kernels_dense.hip)
+hipError_t launchLuSolveDense(int n, int B, double* dWork, const double* dRhs, double* dX, uint32_t* dFlags,
+                              double eps, hipStream_t stream);
+hipError_t launchLuFactorDense(int n, int B, double* dLU, int32_t* dPerm, uint32_t* dFlags, double eps,
+                               hipStream_t stream);
+
 // wave-per-instance kernels for 64 <= N <= 320 (kernels_big.hip)
 size_t bigScratchBytesPerInstance(const GenPlan& pl);
 int bigMaxUnknowns();

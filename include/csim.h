@@ -160,7 +160,8 @@ int64_t csim_tran_num_steps(double tstep, double tstop);
 /* Batched dense solve A x = b with the engine's pivoted LU
  * (Solver::solveLinearSystemLU semantics: first-maximum partial pivoting,
  * tiny pivot -> zero vector).  A [B][n][n] row-major, b/x [B][n], host
- * pointers.  flags [B] optional (CSIM_ST_LU_*).  device: HIP device index.    */
+ * pointers.  flags [B] optional (CSIM_ST_LU_*).  device: HIP device index.
+ * n <= 63 runs LDS-resident, 64 <= n <= 1024 in place in global memory.       */
 int  csim_lu_solve_batch(int32_t device, int32_t n, int32_t B, const double* A,
                          const double* b, double* x, uint32_t* flags);
 

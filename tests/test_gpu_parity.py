@@ -433,6 +433,40 @@ def test_lu_decompose_factors_bitwise_equal_to_oracle():
     assert flags[0] & 0x4
 
 
+def test_lu_dense_systems_beyond_lds_bitwise_equal_to_oracle():
+    """Solver::solveLinearSystemLU / luDecompose for n > 63 (BASELINE configs[3] size: n = 257,
+    528 KB per matrix): the in-place global-memory kernel, fully dense and MNA-like sparse inputs,
+    forced pivoting, a first-maximum tie, a singular system."""
+    from circuitsimulator_amd import lu_decompose_batch, lu_solve_batch
+    rs = np.random.RandomState(5)
+    for n in (64, 100, 257):
+        B = 4
+        A = rs.randn(B, n, n)
+        A[1][rs.rand(n, n) < 0.9] = 0.0                   # sparse like an MNA matrix
+        A[1] += np.eye(n) * 0.7
+        A[2] = A[2][::-1].copy()                          # reversed rows: a swap in almost every column
+        A[3, 5, :] = A[3, 9, :]                           # two equal rows: exact ties, then a tiny pivot
+        A[0, 3, 0] = -A[0, :, 0].__abs__().max()          # tie in column 0 between an early and a later row
+        A[0, 7, 0] = -A[0, 3, 0]
+        b = rs.randn(B, n)
+        x, flags = lu_solve_batch(A, b)
+        LU, perm, dflags = lu_decompose_batch(A)
+        for i in range(B):
+            xo, fo = _orc().solve_lu(A[i], b[i])
+            assert flags[i] == fo, (n, i, flags[i], fo)
+            assert np.array_equal(x[i], xo), (n, i, np.abs(x[i] - xo).max())
+            ok, LUo, permo = _orc().lu_decompose(A[i])
+            assert bool(dflags[i] & 0x4) == (not ok), (n, i)
+            if ok:
+                assert np.array_equal(perm[i], permo), (n, i)
+                assert np.array_equal(LU[i], LUo), (n, i, np.abs(LU[i] - LUo).max())
+    # exactly singular: zero column -> the reference returns the zero vector
+    A = rs.randn(1, 80, 80)
+    A[0, :, 17] = 0.0
+    x, flags = lu_solve_batch(A, rs.randn(1, 80))
+    assert flags[0] & 0x4 and not x.any()
+
+
 def test_cli_writes_the_reference_csv(tmp_path, buffer_nl):
     """csim_cli = the reference's main.cpp phases over the C++ shims (parseNetlist,
     computeDcOperatingPoint, runTransientAnalysisBackwardEuler) -> the reference's CSV."""
