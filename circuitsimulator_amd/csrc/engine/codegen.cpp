@@ -285,6 +285,7 @@ struct VariantOptions {
     int parkBudget;     // how many finished U-row values may be parked in LDS (-1 = all)
     int ckUnroll = 4;   // unroll factor of the per-step checkpoint loop (swept 1/2/4/8/31: 4 best, 31 pins 2N VGPRs)
     bool dcMode = false;// emit the DC operating-point kernel (source ramp + ConvController) instead of the transient
+    int wavesPerEu = 0; // > 0: amdgpu_waves_per_eu(n, n) -- caps registers at 512 / n per lane (tuning aid)
 };
 
 // emits ONE __global__ kernel; returns the number of LDS doubles per lane it uses
@@ -398,7 +399,8 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             << "    const long long SB = B;\n"
             << "    const bool splitFlag = B < 0;              // never true; opaque to the compiler\n";
     } else {
-        src << "extern \"C\" __global__ void __launch_bounds__(64)\n"
+        src << "extern \"C\" __global__ void __launch_bounds__(64)"
+            << (opt.wavesPerEu > 0 ? " __attribute__((amdgpu_waves_per_eu(" + std::to_string(opt.wavesPerEu) + ", " + std::to_string(opt.wavesPerEu) + ")))" : std::string()) << "\n"
             << opt.kernelName << "(const double* __restrict__ params, int B, double dt, long long stepFirst,\n"
             << "                       long long nSteps, const int* __restrict__ probeEq, int nProbe, int outStride,\n"
             << "                       double* __restrict__ wave, double* __restrict__ xio, long long* __restrict__ iters,\n"
@@ -979,7 +981,9 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
             static std::vector<std::string> names;
             names.push_back("csim_tran_sched_kernel_sweep" + std::to_string(k));
             // value >= 1000: checkpoint-unroll sweep (value - 1000) at the lean park budget
-            if (sweep[k] >= 1000) emitVariant({names.back().c_str(), false, false, leanBudget > 0 ? leanBudget : 0, sweep[k] - 1000}, nullptr);
+            // value >= 2000: two waves per SIMD (<= 256 registers per lane) at park budget (value - 2000)
+            if (sweep[k] >= 2000) { VariantOptions o{names.back().c_str(), false, false, sweep[k] - 2000}; o.wavesPerEu = 2; emitVariant(o, nullptr); }
+            else if (sweep[k] >= 1000) emitVariant({names.back().c_str(), false, false, leanBudget > 0 ? leanBudget : 0, sweep[k] - 1000}, nullptr);
             else emitVariant({names.back().c_str(), false, false, sweep[k]}, nullptr);
         }
     }
