@@ -122,7 +122,7 @@ uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch)
         for (std::size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
     };
     auto mixInt = [&](int32_t v) { mixBytes(&v, sizeof v); };
-    mixInt(10);                                           // generator revision
+    mixInt(12);                                           // generator revision
     mixInt(ir.n_unknowns); mixInt(ir.n_node_eq); mixInt(ir.n_branch_eq);
     mixInt(ir.n_elems); mixInt(ir.n_params); mixInt(ir.has_nonlinear);
     for (int e = 0; e < ir.n_elems; ++e) {
@@ -372,10 +372,14 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
                     toLdsParam(sl + o);
                     // lean: source parameters are needed once per time step only -- re-read them
                     // from the table (L2-resident) instead of pinning 6 doubles per source in
-                    // registers for the whole kernel; volatile keeps LICM from hoisting the load
+                    // registers for the whole kernel.  The index carries an offset `vo` that is always 0
+                    // but opaque to the compiler, which keeps LICM from hoisting the loads; a volatile
+                    // access did the same but compiled to flat_load (both wait counters): measured
+                    // 6.59e8 -> 6.88e8 at B = 4096 and 8.97e9 -> 9.86e9 at B = 65 536 (CSIM_CG_VOLATILE: old form)
                     if (!opt.rich)
                         pRef[static_cast<std::size_t>(sl + o)] =
-                            "(*(const volatile double*)&params[" + std::to_string(sl + o) + "LL * SB + bb])";
+                            (std::getenv("CSIM_CG_VOLATILE") ? "(*(const volatile double*)&params[" + std::to_string(sl + o) + "LL * SB + bb])"
+                                                             : "params[" + std::to_string(sl + o) + "LL * SB + bb + vo]");
                 }
                 break;
             case CSIM_NMOS: case CSIM_PMOS:
@@ -466,7 +470,8 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             << "        // baseGmin(scale) (dcanalysis.hpp:45-48), every product and sum rounded separately\n"
             << "        const double gb = __dadd_rn(__dmul_rn(" << lit(K.gmin_high) << ", 1.0 - scale), __dmul_rn(" << lit(K.gmin_low) << ", scale));\n"
             << "        double gminv = gb;\n"
-            << "        double prevErr = INFINITY;\n";
+            << "        double prevErr = INFINITY;\n"
+            << "        const long long vo = splitFlag ? (long long)step : 0LL;\n";
     } else {
         src << "    {\n        const double* xin = xio + bb;\n#pragma unroll 1\n"
             << "        for (int i = 0; i < " << N << "; ++i, xin += SB) X(i) = *xin;\n    }\n";
@@ -490,6 +495,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             << "        const bool live = !dead && !viol && sdone + 1 == s;\n"
             << "        const long long gstep = stepFirst + s;\n"
             << "        const double tNow = (double)(int)gstep * dt;\n"
+            << "        const long long vo = splitFlag ? s : 0LL;   // always 0, but not to the compiler: keeps per-step re-reads in the loop\n"
             << "        if (live) {     // checkpoint: state at the start of this step.  A ROLLED loop: unrolled,\n"
             << "                        // hipcc hoists the N store addresses out of the time loop and pins 2N VGPRs\n"
             << "            double* ck = xio + b;\n"
@@ -693,6 +699,9 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         std::vector<AV> rinv(static_cast<std::size_t>(N));      // 1 / U(k,k)
         int parked = 0;
         const bool groupChecks = std::getenv("CSIM_CG_GROUP") != nullptr;
+        // default: one running maximum per side of the scheduled row (measured +2.7 % at B = 4096 and 65 536
+        // over one comparison per candidate row); CSIM_CG_NOMAXCHECK restores the per-row comparisons
+        const bool maxChecks = std::getenv("CSIM_CG_NOMAXCHECK") == nullptr;
         const int splitEvery = std::getenv("CSIM_CG_SPLIT") ? std::max(1, std::atoi(std::getenv("CSIM_CG_SPLIT"))) : 0;
         for (int k = 0; k < N; ++k) {
             const int p = sc.pivotPos[static_cast<std::size_t>(k)];
@@ -734,6 +743,22 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
                     ++g.st.nCmp;
                 }
                 if (contradiction) g.out << g.ind << pvName << " = true;\n";
+                else if (maxChecks && ap_.kind == AV::DYN) {
+                    // one running maximum per side (rows before / after the scheduled one), then at most three
+                    // tests per column.  fmax ignores a NaN operand exactly like the reference's "> maxVal" scan.
+                    std::string mb, ma;
+                    for (int i = k; i < N; ++i) {
+                        if (i == p) continue;
+                        const AV& ai = at(i, k);
+                        if (ai.isZero()) continue;
+                        const std::string absI = ai.kind == AV::CONST ? lit(std::fabs(ai.c)) : "fabs(" + ai.v + ")";
+                        std::string& m = (i < p) ? mb : ma;
+                        m = m.empty() ? absI : "fmax(" + m + ", " + absI + ")";
+                    }
+                    g.out << g.ind << pvName << " = " << pvName << " || !(" << absP << " >= " << lit(K.lu_eps) << ");\n";
+                    if (!mb.empty()) g.out << g.ind << pvName << " = " << pvName << " || !(" << absP << " > " << mb << ");\n";
+                    if (!ma.empty()) g.out << g.ind << pvName << " = " << pvName << " || !(" << absP << " >= " << ma << ");\n";
+                }
                 else if (groupChecks && !conds.empty()) {
                     // one test (and one block boundary) per column: comparisons combined without short-circuit
                     std::string e;
