@@ -1007,7 +1007,10 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
             names.push_back("csim_tran_sched_kernel_sweep" + std::to_string(k));
             // value >= 1000: checkpoint-unroll sweep (value - 1000) at the lean park budget
             // value >= 2000: two waves per SIMD (<= 256 registers per lane) at park budget (value - 2000)
-            if (sweep[k] >= 2000) { VariantOptions o{names.back().c_str(), false, false, sweep[k] - 2000}; o.wavesPerEu = 2; emitVariant(o, nullptr); }
+            // 4000 + b: launch constants AND per-step terms in LDS, park budget b;  3000 + b: launch constants in LDS
+            if (sweep[k] >= 4000) emitVariant({names.back().c_str(), true, true, sweep[k] - 4000}, nullptr);
+            else if (sweep[k] >= 3000) emitVariant({names.back().c_str(), true, false, sweep[k] - 3000}, nullptr);
+            else if (sweep[k] >= 2000) { VariantOptions o{names.back().c_str(), false, false, sweep[k] - 2000}; o.wavesPerEu = 2; emitVariant(o, nullptr); }
             else if (sweep[k] >= 1000) emitVariant({names.back().c_str(), false, false, leanBudget > 0 ? leanBudget : 0, sweep[k] - 1000}, nullptr);
             else emitVariant({names.back().c_str(), false, false, sweep[k]}, nullptr);
         }
