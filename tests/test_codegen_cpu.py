@@ -1,0 +1,70 @@
+"""Host side of the kernel generator (no GPU): schedule-file parsing, what the generated
+translation unit contains, and that a schedule which contradicts the circuit's constant entries
+is turned into an unconditional fall-back instead of wrong code."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT, netlist_path
+
+CODEGEN = os.path.join(ROOT, "circuitsimulator_amd", "csrc", "build", "csim_codegen")
+SCHED = os.path.join(ROOT, "circuitsimulator_amd", "csrc", "schedules")
+
+
+@pytest.fixture(scope="module")
+def codegen():
+    if not os.path.exists(CODEGEN):
+        import __graft_entry__ as g
+        g.build()
+    assert os.path.exists(CODEGEN)
+    return CODEGEN
+
+
+def _run(codegen, netlist, sched_text, tmp_path):
+    sched = tmp_path / "x.sched"
+    sched.write_text(sched_text)
+    out = tmp_path / "x.hip"
+    p = subprocess.run([codegen, netlist, str(sched), str(out)], capture_output=True, text=True)
+    return p, (out.read_text() if out.exists() else "")
+
+
+def test_shipped_schedule_files_generate_both_kernels(codegen, tmp_path):
+    text = open(os.path.join(SCHED, "dbmixer.sched")).read()
+    p, src = _run(codegen, netlist_path("dbmixer.sp"), text, tmp_path)
+    assert p.returncode == 0, p.stderr
+    topo = p.stdout.strip()
+    assert len(topo) == 16 and os.path.exists(os.path.join(ROOT, "circuitsimulator_amd", "libcsim_sched_%s.so" % topo))
+    for sym in ("csim_tran_sched_kernel(", "csim_dc_sched_kernel(", "csim_sched_launch(", "csim_sched_dc_launch(",
+                "csim_sched_alts(", "csim_sched_dc_alts(", "csim_sched_topology(", "csim_sched_hash("):
+        assert sym in src, sym
+    assert "*nAlts = 1;" in src                      # one transient and one DC sequence
+    # buffer.sched has several transient alternatives and no "dc" line: no DC kernel, a stub launcher
+    text = open(os.path.join(SCHED, "buffer.sched")).read()
+    p, src = _run(codegen, netlist_path("buffer.sp"), text, tmp_path)
+    assert p.returncode == 0, p.stderr
+    assert "csim_dc_sched_kernel(" not in src and "return -1;" in src
+    assert src.count("// alternative schedule") >= 6
+
+
+def test_schedule_file_syntax(codegen, tmp_path):
+    nl = netlist_path("buffer.sp")
+    ok = "0:9,1:10,5:11,7:12,8:12   # comment ; with a semicolon\n- ; 0:9\nDC 0:9,1:10\n"
+    p, src = _run(codegen, nl, ok, tmp_path)
+    assert p.returncode == 0, p.stderr
+    assert "tried in this order: 0:9,1:10,5:11,7:12,8:12 ; - ; 0:9 ; dc 0:9,1:10" in src
+    for bad in ("0:99\n",            # row out of range
+                "5:3\n",             # pivot row above the diagonal
+                "0;9\n",             # not column:row
+                "# only a comment\n"):
+        p, _ = _run(codegen, nl, bad, tmp_path)
+        assert p.returncode != 0, bad
+
+
+def test_schedule_contradicting_constant_entries_falls_back(codegen, tmp_path):
+    """A schedule that demands a structurally ZERO pivot (buffer.sp: the branch row of inductor L2,
+    position 12, has no entry in column 0 = node 103) must compile to 'always violated', not to a
+    division by a zero that the code never materialised."""
+    p, src = _run(codegen, netlist_path("buffer.sp"), "0:12\n", tmp_path)
+    assert p.returncode == 0, p.stderr
+    assert "scheduled pivot is a structural zero" in src
