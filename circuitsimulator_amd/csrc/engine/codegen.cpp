@@ -122,7 +122,7 @@ uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch)
         for (std::size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
     };
     auto mixInt = [&](int32_t v) { mixBytes(&v, sizeof v); };
-    mixInt(14);                                           // generator revision
+    mixInt(15);                                           // generator revision
     mixInt(ir.n_unknowns); mixInt(ir.n_node_eq); mixInt(ir.n_branch_eq);
     mixInt(ir.n_elems); mixInt(ir.n_params); mixInt(ir.has_nonlinear);
     for (int e = 0; e < ir.n_elems; ++e) {
@@ -716,7 +716,13 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         if (splitEvery > 0) {
             if ((k % splitEvery) == 0) g.out << g.ind << "if (splitFlag) asm volatile(\"s_nop 0\");\n";
         } else if (std::getenv("CSIM_CG_NOBARRIER") == nullptr) {
-            g.out << g.ind << "__builtin_amdgcn_sched_barrier(0);\n";
+            const char* until = std::getenv("CSIM_CG_BARRIER_UNTIL");      // tuning aid: barriers for the first columns only
+            // a barrier every 3rd column (swept 1/2/3/4/5/6/8/10 with the branch-free checks: 8.41, 8.46, 8.54, 8.53,
+            // 8.47, 8.49, 8.48, 8.43e8 at B = 4096); CSIM_CG_BARRIER_EVERY overrides
+            const char* every = std::getenv("CSIM_CG_BARRIER_EVERY");
+            const int spacing = every ? std::max(1, std::atoi(every)) : 3;
+            const bool on = (!until || k < std::atoi(until)) && (k % spacing) == 0;
+            if (on) g.out << g.ind << "__builtin_amdgcn_sched_barrier(0);\n";
         }
         // the reference picks the FIRST row attaining the column maximum (solver.hpp:48-56)
             // and fails below 1e-15 (:58-61)
