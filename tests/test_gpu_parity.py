@@ -167,6 +167,28 @@ def test_dbmixer_full_run_nominal(engines, torch_mod, anchors):
         assert abs(xf[0][i] - float(s)) <= TOL * max(abs(float(s)), floor)
 
 
+def test_dbmixer_full_run_monte_carlo_instances(engines, torch_mod):
+    """BASELINE configs[2]/[4] at FULL length: Monte-Carlo instances through all 50 000 steps on the
+    scheduled kernel; per-instance NR totals and the final state against the oracle (three instances;
+    the oracle needs ~3 s each)."""
+    torch = torch_mod
+    nl, eng = engines["dbmixer"]
+    B = 64
+    params = eng.mc_params(12345, 0.05, 0, B)
+    x, dc_it, st = eng.dc(params)
+    iters = torch.zeros(B, dtype=torch.int64, device=x.device)
+    for s0 in range(0, 50000, 5000):
+        eng.tran(params, x, nl.tstep, s0, 5000, iters, st)
+    torch.cuda.synchronize()
+    assert not (st.cpu().numpy().astype(np.uint32) & 0x27).any()
+    ph = params.cpu().numpy()
+    xs, its = x.cpu().numpy(), iters.cpu().numpy()
+    for b in (1, 37, 63):
+        o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstop, want_rows=False)
+        assert o["n_steps"] == 50000 and its[b] == o["iters"], (b, its[b], o["iters"])
+        assert rel_err(xs[:, b], o["x_final"], nl.n_node_eq).max() < TOL
+
+
 # --------------------------------------- scheduled (lane-per-instance) kernels
 
 def test_shipped_netlists_have_scheduled_kernels(engines):
