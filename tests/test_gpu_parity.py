@@ -901,3 +901,105 @@ def test_scheduled_dc_violators_are_replayed_by_the_general_kernel(torch_mod, tm
     assert np.array_equal(it_g.cpu().numpy(), it_s.cpu().numpy())
     assert np.array_equal(st_g.cpu().numpy().astype(np.uint32), sts & NOFB)
     assert rel_err(x_s.cpu().numpy().T, x_g.cpu().numpy().T, nl.n_node_eq).max() < TOL
+
+
+# --------------------------------------------------- randomized netlists (general kernels)
+
+def _random_netlist(rs, n_nodes, n_mos):
+    """A random RLC + MOSFET + source circuit in the reference dialect.  Every node gets a resistive
+    path to ground most of the time; now and then one is left floating on purpose."""
+    nodes = ["n%d" % i for i in range(1, n_nodes + 1)]
+    lines = ["* random circuit", "VDD vdd 0 DC %.3g" % rs.choice([1.8, 2.5, 3.3])]
+    k = 0
+    for nd in nodes:
+        if rs.rand() < 0.9:
+            k += 1
+            lines.append("R%d %s %s %.4g" % (k, nd, rs.choice(["0", "vdd"] + nodes), 10 ** rs.uniform(1.5, 5)))
+    for _ in range(n_nodes):
+        a, b = rs.choice(nodes + ["0", "vdd"], 2, replace=False)
+        k += 1
+        lines.append("R%d %s %s %.4g" % (k, a, b, 10 ** rs.uniform(2, 5)))
+    for i, nd in enumerate(nodes):
+        if rs.rand() < 0.7:
+            lines.append("C%d %s 0 %.4g" % (i + 1, nd, 10 ** rs.uniform(-14, -11)))
+    for i in range(rs.randint(0, 3)):
+        a, b = rs.choice(nodes, 2, replace=False)
+        lines.append("L%d %s %s %.4g" % (i + 1, a, b, 10 ** rs.uniform(-10, -8)))
+    src = rs.choice(nodes)
+    lines.append("VIN %s 0 SIN %.3g %.3g %.4g 0" % (src, rs.uniform(0.5, 1.5), rs.uniform(0.1, 1.0), 10 ** rs.uniform(7, 9)))
+    if rs.rand() < 0.5:
+        lines.append("I1 %s %s %.4g" % (rs.choice(nodes), rs.choice(["0"] + nodes), 10 ** rs.uniform(-6, -4)))
+    for i in range(n_mos):
+        d, g, s_ = rs.choice(nodes + ["vdd"], 3, replace=True)
+        if rs.rand() < 0.5:
+            lines.append("M%d %s %s %s n %.3ge-6 0.35e-6 2" % (i + 1, d, g, rs.choice([s_, "0"]), rs.uniform(5, 40)))
+        else:
+            lines.append("M%d %s %s %s p %.3ge-6 0.35e-6 1" % (i + 1, d, g, rs.choice([s_, "vdd"]), rs.uniform(5, 60)))
+    lines += [".MODEL 1 VT -0.75 MU 5e-2 COX 0.3e-4 LAMBDA 0.05 CJ0 4.0e-14",
+              ".MODEL 2 VT 0.83 MU 1.5e-1 COX 0.3e-4 LAMBDA 0.05 CJ0 4.0e-14",
+              ".TRAN %.3g %.3g" % (1e-10, 4e-9)]
+    return "\n".join(lines) + "\n"
+
+
+def test_random_netlists_general_kernels_vs_oracle(torch_mod):
+    """40 seeded random circuits (3..18 nodes, 0..5 MOSFETs, inductors, floating nodes now and then)
+    through the general DC and transient kernels, three Monte-Carlo instances each, against the oracle:
+    status words and NR counts equal, states within the parity bar.  Covers what the two shipped
+    netlists cannot: arbitrary stamping orders, pivot ties, singular systems, non-convergence."""
+    from circuitsimulator_amd import Engine, Netlist
+    orc = _orc()
+    worst = 0.0
+    n_flagged = 0
+    for seed in range(40):
+        rs = np.random.RandomState(1000 + seed)
+        text = _random_netlist(rs, rs.randint(3, 19), rs.randint(0, 6))
+        nl = Netlist.from_text(text)
+        eng = Engine(nl, 0)
+        B, steps = 3, 40
+        params = eng.mc_params(seed, 0.05, 0, B)
+        r = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+        ph = params.cpu().numpy()
+        for b in range(B):
+            xo, ito, sto = orc.dc(nl.ir_ptr, nl.n_unknowns, ph, b)
+            assert r["dc_iters"][b] == ito, (seed, b, "dc iters", r["dc_iters"][b], ito)
+            assert rel_err(r["x_dc"][:, b], xo, nl.n_node_eq).max() < TOL, (seed, b, "dc x")
+            o = orc.tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstep * steps, want_step_iters=True)
+            dc_bits = sto & 0x1C                                    # DC flags live in the same status word
+            assert (r["status"][b] & NOFB) == (o["status"] | dc_bits), (seed, b, hex(r["status"][b]), hex(o["status"]), hex(sto))
+            n_flagged += int(r["status"][b] != 0)
+            if o["status"] & 0x1:                                   # the reference would have thrown: stopped early
+                continue
+            assert np.array_equal(r["step_iters"][:, b], o["step_iters"]), (seed, b, "tran iters")
+            e = rel_err(r["x"][:, b], o["x_final"], nl.n_node_eq).max()
+            worst = max(worst, e)
+            assert e < TOL, (seed, b, e)
+    print("random netlists: worst relative deviation %.2e, %d flagged instance runs" % (worst, n_flagged))
+
+
+def test_random_netlists_generated_kernels(torch_mod, tmp_path, monkeypatch):
+    """The kernel generator on six of the random circuits: plan, generate, hipcc, load; the generated
+    transient (and, where a few sequences cover the ramp, DC) kernels against the general kernels on a
+    Monte-Carlo batch -- per-step NR counts and status equal, states within the parity bar."""
+    import shutil
+    from circuitsimulator_amd import Engine, Netlist
+    if not (shutil.which("hipcc") or __import__("os").path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available for the JIT")
+    monkeypatch.setenv("CSIM_JIT_DIR", str(tmp_path / "jit"))
+    n_dc_kernels = 0
+    for seed in (3, 8, 14, 20, 27, 36):
+        rs = np.random.RandomState(1000 + seed)
+        nl = Netlist.from_text(_random_netlist(rs, rs.randint(3, 19), rs.randint(0, 6)))
+        eng = Engine(nl, 0)
+        B, steps = 70, 60
+        params = eng.mc_params(seed, 0.05, 0, B)
+        slow = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+        eng.jit_scheduled(params, plan_steps=steps)
+        assert eng.tran_kernel == "scheduled", seed
+        fast = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+        assert np.array_equal(fast["dc_iters"], slow["dc_iters"]), seed
+        assert rel_err(fast["x_dc"].T, slow["x_dc"].T, nl.n_node_eq).max() < TOL, seed
+        assert np.array_equal(fast["step_iters"], slow["step_iters"]), seed
+        assert np.array_equal(fast["status"] & NOFB, slow["status"]), seed
+        assert rel_err(fast["x"].T, slow["x"].T, nl.n_node_eq).max() < TOL, seed
+        n_dc_kernels += int(((fast["status"] & FALLBACK_DC) != 0).any())
+    print("random netlists: %d of 6 circuits had DC instances replayed by the general kernel" % n_dc_kernels)
