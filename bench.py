@@ -31,6 +31,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK_TFLOPS = 78.6 # MI355X FP64 vector peak (256 CUs x 4 SIMDs x 16 FMA lanes x 2 flop x 2.4 GHz)
+
+
+def dense_flops(n):
+    """LU + substitution flops of the reference per NR iteration."""
+    return n * (n - 1) // 2 + (n - 1) * n * (2 * n - 1) // 3 + 2 * n * (n - 1) + n
 
 
 def algorithmic_bytes_per_iter(N):
@@ -240,6 +246,14 @@ def main():
                 "traffic": hbm_traffic_per_launch(nl, eng.tran_kernel, B, S),
                 "algorithmic_bytes_per_unit": abytes,
                 "kernel_avg_ms": avg_kern_s * 1e3,
+            },
+            # the dense LU + substitution flops the reference spends per NR iteration,
+            # n(n-1)/2 + (n-1)n(2n-1)/3 + 2n(n-1) + n, against the FP64 vector peak (the kernels execute far fewer:
+            # structural zeros are never touched)
+            "fp64_dense_equivalent": {
+                "flops_per_unit": dense_flops(nl.n_unknowns),
+                "achieved_tflops": (iters_per_launch / avg_kern_s) * dense_flops(nl.n_unknowns) / 1e12,
+                "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
             },
             "netlist_bcast_ms": bcast_ms,
             "result_gather_ms": gather_ms,
