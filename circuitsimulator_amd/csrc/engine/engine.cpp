@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "codegen.hpp"
@@ -571,9 +572,22 @@ static void decodePivotLog(const std::vector<int32_t>& log, int N, int32_t max_a
     if (n_other) *n_other = other;
 }
 
+static int recordPivotSchedulesImpl(csim_engine* eng, const double* d_params, int32_t B, int32_t instance,
+                                    double tstep, int64_t n_steps, int32_t max_alts, int32_t* pivot_pos,
+                                    int64_t* counts, int32_t* n_alts, int64_t* n_other, uint32_t* inst_status);
+
 int csim_record_pivot_schedules(csim_engine* eng, const double* d_params, int32_t B, int32_t instance,
                                 double tstep, int64_t n_steps, int32_t max_alts, int32_t* pivot_pos,
                                 int64_t* counts, int32_t* n_alts, int64_t* n_other)
+{
+    return recordPivotSchedulesImpl(eng, d_params, B, instance, tstep, n_steps, max_alts, pivot_pos, counts, n_alts,
+                                    n_other, nullptr);
+}
+
+// inst_status (optional): status word of the planned instance after DC + the planned steps
+static int recordPivotSchedulesImpl(csim_engine* eng, const double* d_params, int32_t B, int32_t instance,
+                                    double tstep, int64_t n_steps, int32_t max_alts, int32_t* pivot_pos,
+                                    int64_t* counts, int32_t* n_alts, int64_t* n_other, uint32_t* inst_status)
 {
     if (!eng || !d_params || !pivot_pos || !n_alts || B <= 0 || instance < 0 || instance >= B || n_steps < 0 ||
         !(tstep > 0.0) || max_alts <= 0) {
@@ -613,6 +627,7 @@ int csim_record_pivot_schedules(csim_engine* eng, const double* d_params, int32_
     HIPCHK(hipDeviceSynchronize());
     std::vector<int32_t> log((size_t)logInts);
     HIPCHK(hipMemcpy(log.data(), dLog.p, sizeof(int32_t) * log.size(), hipMemcpyDeviceToHost));
+    if (inst_status) HIPCHK(hipMemcpy(inst_status, dSt.as<uint32_t>() + instance, sizeof(uint32_t), hipMemcpyDeviceToHost));
     decodePivotLog(log, N, max_alts, pivot_pos, counts, n_alts, n_other);
     return CSIM_OK;
 }
@@ -674,17 +689,44 @@ int csim_engine_jit_scheduled(csim_engine* eng, const double* d_params, int32_t 
     const csim_ir* ir = eng->cir.view();
     const int N = ir->n_unknowns;
     const int maxAlts = 4;
-    std::vector<int32_t> pos((size_t)maxAlts * N);
-    int64_t counts[maxAlts] = {0, 0, 0, 0};
-    int32_t nAlts = 0;
-    int64_t other = 0;
-    int rc = csim_record_pivot_schedules(eng, d_params, B, 0, tstep, plan_steps, maxAlts, pos.data(), counts, &nAlts, &other);
-    if (rc) return rc;
-    if (nAlts == 0) { setError("planner saw no successful factorisation"); return CSIM_ERR_UNSUPPORTED; }
+    // Plan on instance 0 (by convention the nominal circuit) and, for circuits small enough that a planning
+    // run costs milliseconds, on three more instances spread over the batch: a switching circuit's Monte-Carlo
+    // samples do not all walk through the same pivot sequences.  Sequences are merged by total use.
+    std::vector<int32_t> planOn = {0};
+    if (!eng->big)
+        for (int32_t cand : {B / 3, (2 * B) / 3, B - 1})
+            if (std::find(planOn.begin(), planOn.end(), cand) == planOn.end()) planOn.push_back(cand);
+    std::vector<std::pair<std::vector<int32_t>, int64_t>> merged;     // (sequence, factorisations)
+    int rc = CSIM_OK;
+    for (int32_t inst : planOn) {
+        const int planMax = 8;
+        std::vector<int32_t> pos((size_t)planMax * N);
+        int64_t counts[planMax] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int32_t n = 0;
+        int64_t other = 0;
+        uint32_t instStatus = 0;
+        rc = recordPivotSchedulesImpl(eng, d_params, B, inst, tstep, plan_steps, planMax, pos.data(), counts, &n, &other,
+                                      &instStatus);
+        if (rc) return rc;
+        // An instance whose Newton iterations do not converge (or that met a failed factorisation) is not a
+        // pattern worth specialising for: its trajectory is chaotic, only the bit-faithful general kernel
+        // reproduces it, and that is where its schedule violations send it.  Instance 0 always counts.
+        const uint32_t trouble = CSIM_ST_TRAN_NONFINITE | CSIM_ST_TRAN_NONCONV | CSIM_ST_LU_TINY_PIVOT |
+                                 CSIM_ST_DC_NONCONV | CSIM_ST_DC_NONFINITE;
+        if (inst != 0 && (instStatus & trouble)) continue;
+        for (int a = 0; a < n; ++a) {
+            std::vector<int32_t> seq(pos.begin() + (size_t)a * N, pos.begin() + (size_t)(a + 1) * N);
+            auto hit = std::find_if(merged.begin(), merged.end(), [&](const auto& m) { return m.first == seq; });
+            if (hit == merged.end()) merged.emplace_back(seq, counts[a]);
+            else hit->second += counts[a];
+        }
+    }
+    if (merged.empty()) { setError("planner saw no successful factorisation"); return CSIM_ERR_UNSUPPORTED; }
+    std::stable_sort(merged.begin(), merged.end(), [](const auto& x, const auto& y) { return x.second > y.second; });
     csim::ScheduleSet sch;
-    for (int a = 0; a < nAlts; ++a) {
+    for (size_t a = 0; a < merged.size() && a < (size_t)maxAlts; ++a) {
         csim::PivotSchedule one = csim::PivotSchedule::identity(N);
-        for (int k = 0; k < N; ++k) one.pivotPos[(size_t)k] = pos[(size_t)a * N + k];
+        for (int k = 0; k < N; ++k) one.pivotPos[(size_t)k] = merged[a].first[(size_t)k];
         sch.alts.push_back(one);
     }
     // The DC operating point of Newton circuits gets its own schedules (planned on the same instance),
