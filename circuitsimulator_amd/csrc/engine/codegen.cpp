@@ -716,12 +716,11 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         if (splitEvery > 0) {
             if ((k % splitEvery) == 0) g.out << g.ind << "if (splitFlag) asm volatile(\"s_nop 0\");\n";
         } else if (std::getenv("CSIM_CG_NOBARRIER") == nullptr) {
-            const char* until = std::getenv("CSIM_CG_BARRIER_UNTIL");      // tuning aid: barriers for the first columns only
             // a barrier every 3rd column (swept 1/2/3/4/5/6/8/10 with the branch-free checks: 8.41, 8.46, 8.54, 8.53,
             // 8.47, 8.49, 8.48, 8.43e8 at B = 4096); CSIM_CG_BARRIER_EVERY overrides
             const char* every = std::getenv("CSIM_CG_BARRIER_EVERY");
             const int spacing = every ? std::max(1, std::atoi(every)) : 3;
-            const bool on = (!until || k < std::atoi(until)) && (k % spacing) == 0;
+            const bool on = (k % spacing) == 0;
             if (on) g.out << g.ind << "__builtin_amdgcn_sched_barrier(0);\n";
         }
         // the reference picks the FIRST row attaining the column maximum (solver.hpp:48-56)
@@ -998,7 +997,7 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "__device__ __forceinline__ double rcp_nr(double a)\n{\n"
         << "    double r = __builtin_amdgcn_rcp(a);\n"
         << "    r = fma(fma(-a, r, 1.0), r, r);\n"
-        << (std::getenv("CSIM_CG_RCP1") ? "" : "    r = fma(fma(-a, r, 1.0), r, r);\n")
+        << "    r = fma(fma(-a, r, 1.0), r, r);\n"
         << "    return r;\n}\n\n";
 
     const int leanBudget = 80 - N;
