@@ -483,6 +483,13 @@ int csim_tran_batch(csim_engine* eng, const double* params, int32_t B, double ts
         HIPCHK(hipMemset(dWave.p, 0, sizeof(double) * waveElems));
     }
 
+    // CSIM_AUTO_JIT=1: a circuit without a prebuilt kernel is specialised on first use (what bench.py does
+    // explicitly), so that callers of the reference-shaped API get the fast path without new code.  Worth it
+    // for long runs only (the compile takes seconds); a failure leaves the general kernel in place.
+    if (!eng->schedLaunch && eng->kernelChoice != 1 && nSteps >= 1000 && std::getenv("CSIM_AUTO_JIT") != nullptr) {
+        if (csim_engine_jit_scheduled(eng, dParams.as<double>(), B, tstep, nSteps < 200 ? nSteps : 200) != CSIM_OK)
+            std::fprintf(stderr, "csim: CSIM_AUTO_JIT: %s -- staying on the general kernel\n", csim_last_error());
+    }
     // t = 0 state: the DC operating point (tanalisis.cpp:112); its status bits stay in dSt
     rc = csim_dc_batch_dev(eng, dParams.as<double>(), B, dX.as<double>(), dIt32.as<int32_t>(), dSt.as<uint32_t>(), nullptr);
     if (rc) return rc;

@@ -1003,3 +1003,31 @@ def test_random_netlists_generated_kernels(torch_mod, tmp_path, monkeypatch):
         assert rel_err(fast["x"].T, slow["x"].T, nl.n_node_eq).max() < TOL, seed
         n_dc_kernels += int(((fast["status"] & FALLBACK_DC) != 0).any())
     print("random netlists: %d of 6 circuits had DC instances replayed by the general kernel" % n_dc_kernels)
+
+
+def test_auto_jit_through_the_reference_shaped_cli(tmp_path):
+    """CSIM_AUTO_JIT=1: csim_cli (= the reference's main.cpp over the C++ shims) on a netlist with no
+    prebuilt kernel specialises it on first use; the CSV equals the general kernel's within the parity bar."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available for the JIT")
+    cli = os.path.join(ROOT, "circuitsimulator_amd", "csim_cli")
+    net = tmp_path / "chain.sp"
+    net.write_text(INVERTER_CHAIN)
+    outs = {}
+    for mode in ("general", "auto_jit"):
+        env = dict(os.environ, CSIM_JIT_DIR=str(tmp_path / "jit"))
+        if mode == "auto_jit":
+            env["CSIM_AUTO_JIT"] = "1"
+        out = tmp_path / (mode + ".csv")
+        p = subprocess.run([cli, str(net), str(out)], capture_output=True, text=True, env=env, timeout=300)
+        assert p.returncode == 0, p.stderr[-500:]
+        outs[mode] = np.loadtxt(out, delimiter=",", skiprows=1)
+    assert any(f.endswith(".so") for f in os.listdir(tmp_path / "jit"))          # a kernel really was generated
+    a, b = outs["general"], outs["auto_jit"]
+    assert a.shape == b.shape and a.shape[0] > 1000
+    nl_nodes = a.shape[1] - 1
+    assert rel_err(b[:, 1:], a[:, 1:], nl_nodes).max() < 1e-8      # CSV carries 10 significant digits
