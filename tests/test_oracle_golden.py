@@ -275,3 +275,22 @@ def test_pulse_pwl_transient_tracks_the_sources():
         assert abs(rows[k, i110] - (0.2 + _pwl(t, [0.0, 2e-9, 5e-9, 9e-9], [0.0, 1.0, 0.5, 2.0]))) < 5e-6
     out = rows[:, 1 + nl.eq_names.index("104")]
     assert out.max() > 2.5 and out.min() < 0.1          # the inverter really switches
+
+
+@pytest.mark.filterwarnings("ignore:divide by zero", "ignore:invalid value")
+def test_pulse_ideal_edges_and_single_point_pwl():
+    """tr = tf = 0 (ideal edges, division by zero inside clamp01 -> +inf -> 1) and a one-point PWL:
+    the oracle against the Python restatement of sim.hpp:80-138, bit for bit, NaN for NaN."""
+    from circuitsimulator_amd import Netlist
+    nl = Netlist.from_text("V1 a 0 PULSE(0 1 1n 0 0 2n 5n)\nV2 b 0 PULSE 0.5 2 1n 0 0 2n\nV3 c 0 DC 1 PWL 2n 0.25\n"
+                           "R1 a 0 1k\nR2 b 0 1k\nR3 c 0 1k\n.TRAN 0.1n 12n\n")
+    p = nl.nominal_params
+    k1, k2, k3 = (nl.eq_names.index(n) for n in ("V1", "V2", "V3"))
+    z = np.zeros(nl.n_unknowns)
+    v1, v2 = list(p[1:8]), list(p[9:16])
+    assert p[16] == 1.0 and list(p[17:19]) == [2 * 1e-9, 0.25]
+    for t in list(np.linspace(0.0, 12e-9, 481)) + [1 * 1e-9, 3 * 1e-9, 6 * 1e-9, 8 * 1e-9]:
+        _, I = orc.stamp_tran(nl.ir_ptr, p, 0, z, z, float(t), 1e-10)
+        want = np.array([_pulse(t, *v1), _pulse(t, *v2), 1.0 + 0.25])
+        got = np.array([I[k1], I[k2], I[k3]])
+        assert np.array_equal(got, want, equal_nan=True), (t, got, want)
