@@ -468,7 +468,7 @@ int csim_tran_batch(csim_engine* eng, const double* params, int32_t B, double ts
     const int64_t nSteps = csim_tran_num_steps(tstep, tstop);
     const int64_t rowsAll = wave_out ? nSteps / out_stride + 1 : 0;
 
-    DevBuf dParams, dX, dXt, dIt32, dIt, dSt, dWave, dWaveT;
+    DevBuf dParams, dX, dXt, dIt32, dIt, dSt, dChunk[2], dChunkT[2];
     int rc = stageParams(eng, params, B, dParams);
     if (rc) return rc;
     HIPCHK(dX.alloc(sizeof(double) * (size_t)N * B));
@@ -477,10 +477,39 @@ int csim_tran_batch(csim_engine* eng, const double* params, int32_t B, double ts
     HIPCHK(dIt.alloc(sizeof(int64_t) * (size_t)B));
     HIPCHK(dSt.alloc(sizeof(uint32_t) * (size_t)B));
     HIPCHK(hipMemset(dIt.p, 0, sizeof(int64_t) * (size_t)B));
-    const size_t waveElems = (size_t)rowsAll * (size_t)(wave_out ? n_probe : 0) * (size_t)B;
+
+    // Waveforms leave the device in chunks of whole output rows: the kernel writes a chunk
+    // [rows][probe][B], it is transposed on the device to the caller's [B][rows][probe] and copied out
+    // with a strided 2-D copy on a second stream while the next chunk is being computed (two buffers).
+    // Device memory for waveforms is bounded by the chunk, not by the run.
+    const int64_t chunkSteps = wave_out ? (out_stride >= 4096 ? (int64_t)out_stride : (4096 / out_stride) * (int64_t)out_stride) : 4096;
+    const int64_t rowsPerChunk = wave_out ? chunkSteps / out_stride + 1 : 0;          // +1: the t = 0 row of the first chunk
+    int64_t firstKept = 0;                                                            // rows with t < tstart are dropped
+    for (int64_t r = 0; wave_out && r < rowsAll; ++r) {
+        const double t = (r == 0) ? 0.0 : static_cast<double>(static_cast<int>(r * out_stride)) * tstep;
+        if (t < tstart) firstKept = r + 1; else break;
+    }
+    const int64_t keep = rowsAll - firstKept;
+    const size_t chunkElems = (size_t)rowsPerChunk * (size_t)(wave_out ? n_probe : 0) * (size_t)B;
+    hipStream_t computeStream = nullptr, copyStream = nullptr;
+    hipEvent_t computed[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
+    struct StreamGuard {
+        hipStream_t *a, *b; hipEvent_t* e1; hipEvent_t* e2;
+        ~StreamGuard() {
+            for (int i = 0; i < 2; ++i) { if (e1[i]) (void)hipEventDestroy(e1[i]); if (e2[i]) (void)hipEventDestroy(e2[i]); }
+            if (*a) (void)hipStreamDestroy(*a);
+            if (*b) (void)hipStreamDestroy(*b);
+        }
+    } guard{&computeStream, &copyStream, computed, copied};
     if (wave_out) {
-        HIPCHK(dWave.alloc(sizeof(double) * waveElems));
-        HIPCHK(hipMemset(dWave.p, 0, sizeof(double) * waveElems));
+        HIPCHK(hipStreamCreateWithFlags(&computeStream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&copyStream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(dChunk[i].alloc(sizeof(double) * chunkElems));
+            HIPCHK(dChunkT[i].alloc(sizeof(double) * chunkElems));
+            HIPCHK(hipEventCreateWithFlags(&computed[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
+        }
     }
 
     // CSIM_AUTO_JIT=1: a circuit without a prebuilt kernel is specialised on first use (what bench.py does
@@ -490,40 +519,48 @@ int csim_tran_batch(csim_engine* eng, const double* params, int32_t B, double ts
         if (csim_engine_jit_scheduled(eng, dParams.as<double>(), B, tstep, nSteps < 200 ? nSteps : 200) != CSIM_OK)
             std::fprintf(stderr, "csim: CSIM_AUTO_JIT: %s -- staying on the general kernel\n", csim_last_error());
     }
+    HIPCHK(hipDeviceSynchronize());                       // uploads and planner work done before the streams start
     // t = 0 state: the DC operating point (tanalisis.cpp:112); its status bits stay in dSt
-    rc = csim_dc_batch_dev(eng, dParams.as<double>(), B, dX.as<double>(), dIt32.as<int32_t>(), dSt.as<uint32_t>(), nullptr);
+    rc = csim_dc_batch_dev(eng, dParams.as<double>(), B, dX.as<double>(), dIt32.as<int32_t>(), dSt.as<uint32_t>(), computeStream);
     if (rc) return rc;
     // time stepping in bounded launches (state carried in dX)
-    const int64_t chunk = 4096;
-    for (int64_t s0 = 0; s0 < nSteps || s0 == 0; s0 += chunk) {
-        const int64_t n = (nSteps - s0) < chunk ? (nSteps - s0) : chunk;
+    int c = 0;
+    for (int64_t s0 = 0; s0 < nSteps || s0 == 0; s0 += chunkSteps, ++c) {
+        const int64_t n = (nSteps - s0) < chunkSteps ? (nSteps - s0) : chunkSteps;
+        const int buf = c & 1;
+        double* dW = nullptr;
+        // global output rows of this chunk: (s0/stride, (s0+n)/stride], plus row 0 in the first chunk
+        const int64_t rLo = (s0 == 0) ? 0 : s0 / out_stride + 1;
+        const int64_t rHi = wave_out ? (s0 + n) / out_stride : -1;               // inclusive
+        const int64_t rowsC = wave_out ? rHi - rLo + 1 : 0;
+        if (wave_out && rowsC > 0) {
+            if (c >= 2) HIPCHK(hipStreamWaitEvent(computeStream, copied[buf], 0));  // buffer free again?
+            HIPCHK(hipMemsetAsync(dChunk[buf].p, 0, sizeof(double) * (size_t)rowsC * n_probe * B, computeStream));
+            // the kernels index rows globally: shift the base so that row rLo lands on the chunk's first row
+            dW = dChunk[buf].as<double>() - (ptrdiff_t)rLo * n_probe * B;
+        }
         rc = csim_tran_batch_dev(eng, dParams.as<double>(), B, tstep, s0, n, probe_eq, n_probe, out_stride,
-                                 wave_out ? dWave.as<double>() : nullptr, dX.as<double>(), dIt.as<int64_t>(),
-                                 dSt.as<uint32_t>(), nullptr, nullptr);
+                                 dW, dX.as<double>(), dIt.as<int64_t>(), dSt.as<uint32_t>(), nullptr, computeStream);
         if (rc) return rc;
+        if (wave_out && rowsC > 0) {
+            HIPCHK(csim::launchTranspose(dChunk[buf].as<double>(), dChunkT[buf].as<double>(), (int)(rowsC * n_probe), B, computeStream));
+            HIPCHK(hipEventRecord(computed[buf], computeStream));
+            const int64_t skip = firstKept > rLo ? (firstKept - rLo < rowsC ? firstKept - rLo : rowsC) : 0;   // leading rows before tstart
+            if (rowsC - skip > 0) {
+                HIPCHK(hipStreamWaitEvent(copyStream, computed[buf], 0));
+                HIPCHK(hipMemcpy2DAsync(wave_out + (size_t)(rLo + skip - firstKept) * n_probe, sizeof(double) * (size_t)keep * n_probe,
+                                        dChunkT[buf].as<double>() + (size_t)skip * n_probe, sizeof(double) * (size_t)rowsC * n_probe,
+                                        sizeof(double) * (size_t)(rowsC - skip) * n_probe, (size_t)B, hipMemcpyDeviceToHost, copyStream));
+            }
+            HIPCHK(hipEventRecord(copied[buf], copyStream));
+        }
         if (nSteps == 0) break;
     }
-    HIPCHK(csim::launchTranspose(dX.as<double>(), dXt.as<double>(), N, B, nullptr));
+    HIPCHK(csim::launchTranspose(dX.as<double>(), dXt.as<double>(), N, B, computeStream));
     HIPCHK(hipDeviceSynchronize());
     if (x_final)  HIPCHK(hipMemcpy(x_final, dXt.p, sizeof(double) * (size_t)N * B, hipMemcpyDeviceToHost));
     if (nr_iters) HIPCHK(hipMemcpy(nr_iters, dIt.p, sizeof(int64_t) * (size_t)B, hipMemcpyDeviceToHost));
     if (status)   HIPCHK(hipMemcpy(status, dSt.p, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost));
-
-    if (wave_out) {
-        // device [rows][probe][B] -> host [B][rows][probe], dropping rows with t < tstart
-        std::vector<double> h(waveElems);
-        HIPCHK(hipMemcpy(h.data(), dWave.p, sizeof(double) * waveElems, hipMemcpyDeviceToHost));
-        int64_t firstKept = 0;
-        for (int64_t r = 0; r < rowsAll; ++r) {
-            const double t = (r == 0) ? 0.0 : static_cast<double>(static_cast<int>(r * out_stride)) * tstep;
-            if (t < tstart) firstKept = r + 1; else break;
-        }
-        const int64_t keep = rowsAll - firstKept;
-        for (int64_t b = 0; b < B; ++b)
-            for (int64_t r = 0; r < keep; ++r)
-                for (int q = 0; q < n_probe; ++q)
-                    wave_out[(b * keep + r) * n_probe + q] = h[((size_t)(r + firstKept) * n_probe + q) * B + b];
-    }
     return CSIM_OK;
 }
 

@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=1600)
+    ap.add_argument("--heavy", type=int, default=0, help="also time a run of this many steps that returns every unknown at every step")
     a = ap.parse_args()
     import numpy as np
     from circuitsimulator_amd import Engine, Netlist
@@ -26,12 +27,16 @@ def main():
     tstop = nl.tstep * a.steps
     eng.tran_host(params, tstep=nl.tstep, tstop=nl.tstep * 8)                        # warm-up (allocations, module load)
     out = {}
-    for label, probes, stride in (("final state only", None, 1), ("2 probes, every 10th step", nl.probes[:2], 10)):
+    cases = [("final state only", None, 1, a.steps), ("2 probes, every 10th step", nl.probes[:2], 10, a.steps)]
+    if a.heavy:
+        cases.append(("every unknown, every step, %d steps" % a.heavy, list(range(nl.n_unknowns)), 1, a.heavy))
+    for label, probes, stride, steps in cases:
         t0 = time.perf_counter()
-        wave, xf, it, st = eng.tran_host(params, tstep=nl.tstep, tstop=tstop, probes=probes, out_stride=stride)
+        wave, xf, it, st = eng.tran_host(params, tstep=nl.tstep, tstop=nl.tstep * steps, probes=probes, out_stride=stride)
         dt = time.perf_counter() - t0
         out[label] = {"seconds": dt, "nr_iters": int(it.sum()), "nr_iter_inst_per_s": float(it.sum() / dt),
-                      "flagged": int((st & 0x1F).astype(bool).sum())}
+                      "flagged": int((st & 0x1F).astype(bool).sum()),
+                      "waveform_GB": (wave.nbytes / 1e9) if wave is not None else 0.0}
     print(json.dumps({"batch": a.batch, "steps": a.steps, "host_api": out}))
 
 
