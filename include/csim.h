@@ -148,7 +148,10 @@ int  csim_dc_batch(csim_engine* eng, const double* params, int32_t B,
                    double* x_out, int32_t* nr_iters, uint32_t* status);
 /* Runs DC then the whole transient.  wave_out optional
  * [B][n_rows][n_probe], n_rows = floor(nSteps/out_stride)+1 minus rows with
- * t < tstart (suppressed like dumpRow, src/tanalisis.cpp:208-209).           */
+ * t < tstart (suppressed like dumpRow, src/tanalisis.cpp:208-209).  Waveforms
+ * are streamed out in chunks while the next chunk is computed; device memory
+ * does not grow with the length of the run.  CSIM_AUTO_JIT=1 in the
+ * environment specialises a circuit without a prebuilt kernel on first use.   */
 int  csim_tran_batch(csim_engine* eng, const double* params, int32_t B,
                      double tstep, double tstop, double tstart,
                      const int32_t* probe_eq, int32_t n_probe, int32_t out_stride,
