@@ -294,3 +294,19 @@ def test_pulse_ideal_edges_and_single_point_pwl():
         want = np.array([_pulse(t, *v1), _pulse(t, *v2), 1.0 + 0.25])
         got = np.array([I[k1], I[k2], I[k3]])
         assert np.array_equal(got, want, equal_nan=True), (t, got, want)
+
+
+def test_oracle_self_fingerprints():
+    """Regression guard, not a parity pin: the oracle's output for inputs without a recorded reference output
+    (PULSE/PWL sources, a 32-node RC ladder) still equals what tools/make_oracle_regression.py recorded."""
+    import json
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_oracle_regression as mk
+    from circuitsimulator_amd import Netlist
+    from circuitsimulator_amd.workloads import rc_ladder_netlist
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_regression.json")))
+    assert mk.fingerprint(Netlist.from_file(netlist_path("pulse_pwl.sp")), orc) == want["pulse_pwl"]
+    assert mk.fingerprint(Netlist.from_text(rc_ladder_netlist(32)), orc) == want["rc_ladder_32"]
