@@ -112,9 +112,13 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the engine has no CPU path", file=sys.stderr)
         sys.exit(3)
+    # Rehearsal on a one-GPU box (not the measured configuration): CSIM_SHARE_GPU=1 maps every rank to device 0
+    # and CSIM_DIST_BACKEND=gloo replaces RCCL, which refuses two ranks on one device.  The data path is the same.
+    if os.environ.get("CSIM_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
-    shard.init_process_group("nccl")
+    shard.init_process_group(os.environ.get("CSIM_DIST_BACKEND", "nccl"))
 
     # ---- netlist: rank 0 reads, RCCL broadcast, every rank parses ------------
     t0 = time.perf_counter()

@@ -52,7 +52,11 @@ def init_process_group(backend=None):
 
 
 def _dev(device):
+    """Device the collectives' tensors live on: the caller's, except under gloo (CPU tensors)."""
     import torch
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo":
+        return torch.device("cpu")
     return torch.device(device) if device is not None else torch.device("cpu")
 
 
@@ -92,11 +96,14 @@ def all_gather_instances(local, total, device=None):
     sizes = [shard_range(total, r, world) for r in range(world)]
     bmax = max(hi - lo for lo, hi in sizes)
     lead = tuple(local.shape[:-1])
+    home = local.device
+    if dist.get_backend() == "gloo":
+        local = local.cpu()
     pad = torch.zeros(lead + (bmax,), dtype=local.dtype, device=local.device)
     pad[..., :local.shape[-1]] = local
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad.contiguous())
-    return torch.cat([p[..., :hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=-1)
+    return torch.cat([p[..., :hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=-1).to(home)
 
 
 def all_reduce_sum(value, device=None):
@@ -105,9 +112,14 @@ def all_reduce_sum(value, device=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return value
-    t = value if torch.is_tensor(value) else torch.tensor([value], dtype=torch.float64, device=_dev(device))
+    if torch.is_tensor(value):
+        home = value.device
+        t = value.to(_dev(home))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.to(home)
+    t = torch.tensor([value], dtype=torch.float64, device=_dev(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t if torch.is_tensor(value) else t.item()
+    return t.item()
 
 
 def all_reduce_max(value, device=None):
