@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""One-off fuzz of the kernel generator: seeded random circuits are planned, generated, compiled (hipcc) and
+run; generated kernels (transient and DC) must agree with the general kernels on a Monte-Carlo batch.
+
+    python tools/fuzz_generated.py [--first 3000] [--count 40]
+"""
+import argparse
+import importlib.util
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--first", type=int, default=3000)
+    ap.add_argument("--count", type=int, default=40)
+    a = ap.parse_args()
+    import numpy as np
+    import torch
+    os.environ.setdefault("CSIM_JIT_DIR", "/tmp/csim_jit_fuzz")
+    spec = importlib.util.spec_from_file_location("tgp", os.path.join(ROOT, "tests", "test_gpu_parity.py"))
+    t = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(t)
+    from circuitsimulator_amd import Engine, Netlist
+    bad = 0
+    n_fb = 0
+    for seed in range(a.first, a.first + a.count):
+        rs = np.random.RandomState(seed)
+        nl = Netlist.from_text(t._random_netlist(rs, rs.randint(3, 25), rs.randint(0, 8)))
+        eng = Engine(nl, 0)
+        B, steps = 70, 50
+        params = eng.mc_params(seed, 0.05, 0, B)
+        slow = t._run_tran(torch, eng, params, steps, nl.tstep, want_step_iters=True)
+        try:
+            eng.jit_scheduled(params, plan_steps=steps)
+        except Exception as e:
+            print("seed %d N=%d: JIT refused: %s" % (seed, nl.n_unknowns, e), flush=True)
+            continue
+        fast = t._run_tran(torch, eng, params, steps, nl.tstep, want_step_iters=True)
+        clean = (slow["status"] == 0)                    # converged instances: the strict bar applies
+        problems = []
+        if not np.array_equal(fast["dc_iters"][clean], slow["dc_iters"][clean]):
+            problems.append("dc iters")
+        if not np.array_equal(fast["step_iters"][:, clean], slow["step_iters"][:, clean]):
+            problems.append("tran iters")
+        if not np.array_equal((fast["status"] & t.NOFB)[clean], slow["status"][clean]):
+            problems.append("status")
+        if clean.any():
+            e = t.rel_err(fast["x"].T[clean], slow["x"].T[clean], nl.n_node_eq).max()
+            if e >= t.TOL:
+                problems.append("x deviates %.2e" % e)
+        n_fb += int(((fast["status"] & 0xA0) != 0).sum())
+        if problems:
+            bad += 1
+            print("seed %d N=%d (%d clean of %d): %s" % (seed, nl.n_unknowns, int(clean.sum()), B, "; ".join(problems)), flush=True)
+        eng.close()
+    print("fuzz: %d circuits, %d with mismatches, %d instance runs replayed by the general kernels" % (a.count, bad, n_fb))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
