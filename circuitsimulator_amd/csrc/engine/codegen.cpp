@@ -100,9 +100,28 @@ std::string ScheduleSet::str() const
     return o;
 }
 
-uint64_t scheduleHash(const csim_ir& ir, const ScheduleSet& set)
+bool GeneratorOptions::set(const std::string& keyval)
+{
+    const std::size_t eq = keyval.find('=');
+    if (eq == std::string::npos) return false;
+    const std::string key = keyval.substr(0, eq), val = keyval.substr(eq + 1);
+    if (key == "barrier_every") { barrierEvery = std::max(0, std::atoi(val.c_str())); return true; }
+    if (key == "sweep") {
+        sweep.clear();
+        std::size_t i = 0;
+        while (i < val.size()) { sweep.push_back(std::atoi(val.c_str() + i)); i = val.find(',', i); if (i == std::string::npos) break; ++i; }
+        return true;
+    }
+    return false;
+}
+
+uint64_t scheduleHash(const csim_ir& ir, const ScheduleSet& set, const GeneratorOptions& gopt)
 {
     uint64_t h = scheduleHash(ir, set.alts.empty() ? PivotSchedule::identity(ir.n_unknowns) : set.alts[0]);
+    // everything that changes the emitted code is part of the identity of a generated library
+    auto mix = [&h](uint64_t v) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); };
+    mix(static_cast<uint64_t>(gopt.barrierEvery) + 1);
+    for (int v : gopt.sweep) mix(static_cast<uint64_t>(static_cast<int64_t>(v)) ^ 0x5bd1e995ull);
     for (std::size_t a = 1; a < set.alts.size(); ++a) {
         h ^= 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
         for (int p : set.alts[a].pivotPos) { h ^= static_cast<uint64_t>(p + 1); h *= 1099511628211ull; }
@@ -122,7 +141,7 @@ uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch)
         for (std::size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
     };
     auto mixInt = [&](int32_t v) { mixBytes(&v, sizeof v); };
-    mixInt(15);                                           // generator revision
+    mixInt(kGeneratorRevision);
     mixInt(ir.n_unknowns); mixInt(ir.n_node_eq); mixInt(ir.n_branch_eq);
     mixInt(ir.n_elems); mixInt(ir.n_params); mixInt(ir.has_nonlinear);
     for (int e = 0; e < ir.n_elems; ++e) {
@@ -290,7 +309,7 @@ struct VariantOptions {
 
 // emits ONE __global__ kernel; returns the number of LDS doubles per lane it uses
 int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& ap, const ScheduleSet& set,
-               const VariantOptions& opt, CodegenStats* statsOut)
+               const VariantOptions& opt, const GeneratorOptions& gopt, CodegenStats* statsOut)
 {
     const int N = ir.n_unknowns;
     const int LD = ap.LD;
@@ -375,11 +394,9 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
                     // registers for the whole kernel.  The index carries an offset `vo` that is always 0
                     // but opaque to the compiler, which keeps LICM from hoisting the loads; a volatile
                     // access did the same but compiled to flat_load (both wait counters): measured
-                    // 6.59e8 -> 6.88e8 at B = 4096 and 8.97e9 -> 9.86e9 at B = 65 536 (CSIM_CG_VOLATILE: old form)
+                    // 6.59e8 -> 6.88e8 at B = 4096 and 8.97e9 -> 9.86e9 at B = 65 536
                     if (!opt.rich)
-                        pRef[static_cast<std::size_t>(sl + o)] =
-                            (std::getenv("CSIM_CG_VOLATILE") ? "(*(const volatile double*)&params[" + std::to_string(sl + o) + "LL * SB + bb])"
-                                                             : "params[" + std::to_string(sl + o) + "LL * SB + bb + vo]");
+                        pRef[static_cast<std::size_t>(sl + o)] = "params[" + std::to_string(sl + o) + "LL * SB + bb + vo]";
                 }
                 break;
             case CSIM_NMOS: case CSIM_PMOS:
@@ -394,7 +411,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         src << "extern \"C\" __global__ void __launch_bounds__(64)\n"
             << opt.kernelName << "(const double* __restrict__ params, int B, double* __restrict__ xout,\n"
             << "                       int* __restrict__ iters, unsigned* __restrict__ status,\n"
-            << "                       unsigned char* __restrict__ fallback)\n{\n"
+            << "                       unsigned char* __restrict__ fallback, int* __restrict__ violFlag)\n{\n"
             << "    __shared__ double lds[@LDS_DOUBLES@ * 64];\n"
             << "    const int lane = threadIdx.x;\n"
             << "    const int b = blockIdx.x * 64 + threadIdx.x;\n"
@@ -409,7 +426,8 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             << "                       long long nSteps, const int* __restrict__ probeEq, int nProbe, int outStride,\n"
             << "                       double* __restrict__ wave, double* __restrict__ xio, long long* __restrict__ iters,\n"
             << "                       unsigned* __restrict__ status, int* __restrict__ stepIters,\n"
-            << "                       unsigned char* __restrict__ fallback, int* __restrict__ done)\n{\n"
+            << "                       unsigned char* __restrict__ fallback, int* __restrict__ done,\n"
+            << "                       int* __restrict__ violFlag)\n{\n"
             << "    __shared__ double lds[@LDS_DOUBLES@ * 64];\n"
             << "    const int lane = threadIdx.x;\n"
             << "    const int b = blockIdx.x * 64 + threadIdx.x;\n"
@@ -698,32 +716,17 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         // ---- elimination with the scheduled pivots (solver.hpp:46-77), RHS carried along
         std::vector<AV> rinv(static_cast<std::size_t>(N));      // 1 / U(k,k)
         int parked = 0;
-        const bool groupChecks = std::getenv("CSIM_CG_GROUP") != nullptr;
-        // default: one running maximum per side of the scheduled row (measured +2.7 % at B = 4096 and 65 536
-        // over one comparison per candidate row); CSIM_CG_NOMAXCHECK restores the per-row comparisons
-        const bool maxChecks = std::getenv("CSIM_CG_NOMAXCHECK") == nullptr;
-        const int splitEvery = std::getenv("CSIM_CG_SPLIT") ? std::max(1, std::atoi(std::getenv("CSIM_CG_SPLIT"))) : 0;
         for (int k = 0; k < N; ++k) {
             const int p = sc.pivotPos[static_cast<std::size_t>(k)];
             const AV ap_ = at(p, k);
             g.out << g.ind << "// column " << k << ": pivot row position " << p << "\n";
-            // A scheduling barrier per column.  hipcc schedules each basic block for ILP and inflates the
-        // live set of this 3000-instruction body; with the barrier the allocator ends at 86 spilled
-        // registers, without it at ~200 (measured 6.5e8 vs 5.1e8 NR-iter*inst/s at B = 4096).  The
-        // short-circuit "pv = pv || ..." chains below split blocks to the same effect (branch-free
-        // "|=" was measured 37 % slower).  CSIM_CG_SPLIT=n swaps the barrier for a real block boundary
-        // (scalar branch on an opaque never-true flag) every n columns: measured equal within noise.
-        if (splitEvery > 0) {
-            if ((k % splitEvery) == 0) g.out << g.ind << "if (splitFlag) asm volatile(\"s_nop 0\");\n";
-        } else if (std::getenv("CSIM_CG_NOBARRIER") == nullptr) {
-            // a barrier every 3rd column (swept 1/2/3/4/5/6/8/10 with the branch-free checks: 8.41, 8.46, 8.54, 8.53,
-            // 8.47, 8.49, 8.48, 8.43e8 at B = 4096); CSIM_CG_BARRIER_EVERY overrides
-            const char* every = std::getenv("CSIM_CG_BARRIER_EVERY");
-            const int spacing = every ? std::max(1, std::atoi(every)) : 3;
-            const bool on = (k % spacing) == 0;
-            if (on) g.out << g.ind << "__builtin_amdgcn_sched_barrier(0);\n";
-        }
-        // the reference picks the FIRST row attaining the column maximum (solver.hpp:48-56)
+            // A scheduling barrier every few columns.  hipcc schedules each basic block for ILP and inflates
+            // the live set of this 3000-instruction body; with barriers the allocator ends at 86 spilled
+            // registers, without at ~200 (measured 6.5e8 vs 5.1e8 NR-iter*inst/s at B = 4096).  Spacing swept
+            // 1/2/3/4/5/6/8/10 with the branch-free checks: 8.41, 8.46, 8.54, 8.53, 8.47, 8.49, 8.48, 8.43e8
+            // at B = 4096; a real block boundary (scalar branch on an opaque flag) measured equal within noise.
+            if (gopt.barrierEvery > 0 && (k % gopt.barrierEvery) == 0) g.out << g.ind << "__builtin_amdgcn_sched_barrier(0);\n";
+            // the reference picks the FIRST row attaining the column maximum (solver.hpp:48-56)
             // and fails below 1e-15 (:58-61)
             if (ap_.isZero()) {
                 g.out << g.ind << pvName << " = true;   // scheduled pivot is a structural zero\n";
@@ -748,9 +751,11 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
                     ++g.st.nCmp;
                 }
                 if (contradiction) g.out << g.ind << pvName << " = true;\n";
-                else if (maxChecks && ap_.kind == AV::DYN) {
-                    // one running maximum per side (rows before / after the scheduled one), then at most three
-                    // tests per column.  fmax ignores a NaN operand exactly like the reference's "> maxVal" scan.
+                else if (ap_.kind == AV::DYN) {
+                    // one running maximum per side (rows before / after the scheduled one), then at most two
+                    // tests per column, accumulated WITHOUT branches ("|=": 8.2e8 vs 6.9e8 at B = 4096 for
+                    // short-circuit "||" chains) with 1e-15 folded into the later-rows maximum (+1.9 %).
+                    // fmax ignores a NaN operand exactly like the reference's "> maxVal" scan.
                     std::string mb, ma;
                     for (int i = k; i < N; ++i) {
                         if (i == p) continue;
@@ -760,35 +765,12 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
                         std::string& m = (i < p) ? mb : ma;
                         m = m.empty() ? absI : "fmax(" + m + ", " + absI + ")";
                     }
-                    // Accumulated WITHOUT branches ("|="): with three tests per column the straight-line form wins
-                    // (8.2e8 vs 6.9e8 at B = 4096 for short-circuit "||" chains, whose block boundaries had
-                    // helped when there was one test per candidate row).  CSIM_CG_MAXMODE=branch|group: old forms.
-                    const char* mode = std::getenv("CSIM_CG_MAXMODE");
-                    const bool epsInMax = std::getenv("CSIM_CG_NOEPSMAX") == nullptr;   // eps folded into the running maximum: +1.9 %
-                    std::string e;
-                    if (epsInMax && !ma.empty()) e = "(" + absP + " >= fmax(" + ma + ", " + lit(K.lu_eps) + "))";
-                    else {
-                        e = "(" + absP + " >= " + lit(K.lu_eps) + ")";
-                        if (!ma.empty()) e += " & (" + absP + " >= " + ma + ")";
-                    }
+                    std::string e = ma.empty() ? "(" + absP + " >= " + lit(K.lu_eps) + ")"
+                                               : "(" + absP + " >= fmax(" + ma + ", " + lit(K.lu_eps) + "))";
                     if (!mb.empty()) e += " & (" + absP + " > " + mb + ")";
-                    if (mode && std::string(mode) == "group") {
-                        g.out << g.ind << pvName << " = " << pvName << " || !(" << e << ");\n";
-                    } else if (mode && std::string(mode) == "branch") {
-                        g.out << g.ind << pvName << " = " << pvName << " || !(" << absP << " >= " << lit(K.lu_eps) << ");\n";
-                        if (!mb.empty()) g.out << g.ind << pvName << " = " << pvName << " || !(" << absP << " > " << mb << ");\n";
-                        if (!ma.empty()) g.out << g.ind << pvName << " = " << pvName << " || !(" << absP << " >= " << ma << ");\n";
-                    } else {
-                        g.out << g.ind << pvName << " |= !(" << e << ");\n";
-                    }
-                }
-                else if (groupChecks && !conds.empty()) {
-                    // one test (and one block boundary) per column: comparisons combined without short-circuit
-                    std::string e;
-                    for (std::size_t c = 0; c < conds.size(); ++c) e += (c ? " & " : "") + conds[c];
-                    g.out << g.ind << pvName << " = " << pvName << " || !(" << e << ");\n";
+                    g.out << g.ind << pvName << " |= !(" << e << ");\n";
                 } else {
-                    for (const std::string& c : conds) g.out << g.ind << pvName << " = " << pvName << " || !" << c << ";\n";
+                    for (const std::string& c : conds) g.out << g.ind << pvName << " |= !" << c << ";\n";
                 }
             }
             if (p != k) {
@@ -903,14 +885,22 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
           << g.ind << "        gminv = gnext;\n"
           << g.ind << "        prevErr = err;\n"
           << g.ind << "        if (err < " << lit(K.dc_tol) << ") active = false;                                 // :150\n"
-          << g.ind << "        else if (iter == " << (K.dc_max_iters - 1) << ") st |= ST_DC_NONCONV;             // :153-158\n"
+          // :153-158.  A ramp step that ends at the cap is common and harmless while the ramp goes on (the
+          // damped iteration is a slow contraction: dbmixer ends 9 of its 10 ramp steps there).  When the
+          // FINAL ramp step ends at the cap the returned operating point is wherever the trajectory
+          // stopped, not a fixed point, and only bit-faithful arithmetic reproduces the reference's: the
+          // instance is replayed by the general kernel.
+          << g.ind << "        else if (iter == " << (K.dc_max_iters - 1) << ") {\n"
+          << g.ind << "            if (step == " << K.dc_ramp_steps << ") { viol = true; active = false; }\n"
+          << g.ind << "            else st |= ST_DC_NONCONV;\n"
+          << g.ind << "        }\n"
           << g.ind << "    }\n"
           << g.ind << "}\n";
         src << g.out.str();
         src << i2 << "}\n"      // NR loop
             << "    }\n\n"     // ramp loop
             << "    if (inb) {\n"
-            << "        if (viol) fallback[b] = 1;\n"
+            << "        if (viol) { fallback[b] = 1; *violFlag = 1; }\n"
             << "        else {\n"
             << "            double* xo = xout + b;\n#pragma unroll 1\n"
             << "            for (int i = 0; i < " << N << "; ++i, xo += SB) *xo = X(i);\n"
@@ -936,8 +926,13 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
           << g.ind << "    else {\n"
           << g.ind << "        ++it;\n";
         for (int i = 0; i < N; ++i) o << g.ind << "        X(" << i << ") = xn" << i << ";\n";
+        // NR cap reached (tanalisis.cpp:372-376): the reference warns and moves on with the last iterate.
+        // A Newton iteration that does not converge is chaotic -- the 1e-16 of FMA contraction in this
+        // kernel grows to +-1-2 iterations per step and 4e-7 in the state -- so such a step is treated like
+        // a failed pivot check: the lane stops at the step's checkpoint and the bit-faithful general
+        // kernel redoes the step (and sets CSIM_ST_TRAN_NONCONV).
         o << g.ind << "        if (err < " << lit(K.tran_tol) << ") active = false;\n"
-          << g.ind << "        else if (iter == " << (K.tran_max_iters - 1) << ") st |= ST_TRAN_NONCONV;\n"
+          << g.ind << "        else if (iter == " << (K.tran_max_iters - 1) << ") { viol = true; active = false; }\n"
           << g.ind << "    }\n"
           << g.ind << "}\n";
 
@@ -954,7 +949,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             << i2 << "}\n"
             << "    }\n\n"
             << "    if (inb) {\n"
-            << "        if (viol) fallback[b] = 1;               // xio holds the checkpoint of the step that failed\n"
+            << "        if (viol) { fallback[b] = 1; *violFlag = 1; }   // xio holds the checkpoint of the step that failed\n"
             << "        else {\n";
         src << "            double* xo = xio + b;\n#pragma unroll 1\n"
             << "            for (int i = 0; i < " << N << "; ++i, xo += SB) *xo = X(i);\n"
@@ -974,10 +969,10 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
 } // namespace
 
 std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, const ScheduleSet& set,
-                                     const std::string& label, CodegenStats* statsOut)
+                                     const std::string& label, CodegenStats* statsOut, const GeneratorOptions& gopt)
 {
     const int N = ir.n_unknowns;
-    const uint64_t hash = scheduleHash(ir, set);
+    const uint64_t hash = scheduleHash(ir, set, gopt);
     if (set.alts.empty()) return std::string();
     std::ostringstream src;
     src << "// GENERATED by circuitsimulator_amd/csrc/engine/codegen.cpp -- do not edit.\n"
@@ -1004,7 +999,7 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     // a variant is emitted only if its LDS image fits one CU (163 840 B)
     auto emitVariant = [&](const VariantOptions& opt, CodegenStats* st) {
         std::ostringstream k;
-        const int ldsDoubles = emitKernel(k, ir, ap, set, opt, st);
+        const int ldsDoubles = emitKernel(k, ir, ap, set, opt, gopt, st);
         if (ldsDoubles * 512 > 160 * 1024) return -1;
         std::string text = k.str();
         const std::string token = "@LDS_DOUBLES@";
@@ -1020,11 +1015,8 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     // rich: same residency, every finished U row parked (more LDS per wave: fewer waves per CU)
     const int ldsRich = emitVariant({"csim_tran_sched_kernel_rich", false, false, -1}, nullptr);
     const bool haveRich = ldsRich >= 0;
-    std::vector<int> sweep;
-    if (const char* sw = std::getenv("CSIM_CG_SWEEP")) {      // tuning aid: "0,8,16,24,32" park budgets
-        std::string t(sw);
-        std::size_t i = 0;
-        while (i < t.size()) { sweep.push_back(std::atoi(t.c_str() + i)); i = t.find(',', i); if (i == std::string::npos) break; ++i; }
+    const std::vector<int>& sweep = gopt.sweep;      // tuning aid (csim_codegen --sweep): extra kernels
+    {
         for (std::size_t k = 0; k < sweep.size(); ++k) {
             static std::vector<std::string> names;
             names.push_back("csim_tran_sched_kernel_sweep" + std::to_string(k));
@@ -1074,37 +1066,37 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     }
     src << "};\n    *nAlts = " << (haveDc ? set.dcAlts.size() : 0) << ";\n    *n = " << N << ";\n    return table;\n}\n"
         << "extern \"C\" int csim_sched_dc_launch(const double* params, int B, double* xout, int* iters, unsigned* status,\n"
-        << "                                    unsigned char* fallback, void* stream)\n{\n";
+        << "                                    unsigned char* fallback, int* violFlag, void* stream)\n{\n";
     if (haveDc)
         src << "    if (B <= 0) return 0;\n"
             << "    hipLaunchKernelGGL(csim_dc_sched_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream,\n"
-            << "                       params, B, xout, iters, status, fallback);\n"
+            << "                       params, B, xout, iters, status, fallback, violFlag);\n"
             << "    return (int)hipGetLastError();\n}\n";
     else
-        src << "    (void)params; (void)B; (void)xout; (void)iters; (void)status; (void)fallback; (void)stream;\n    return -1;\n}\n";
+        src << "    (void)params; (void)B; (void)xout; (void)iters; (void)status; (void)fallback; (void)violFlag; (void)stream;\n    return -1;\n}\n";
     src << "// variant: 0/1 = lean (measured fastest at every batch size: park-budget sweep in DESIGN.md),\n"
         << "//          2 = rich (tuning aid), 10+k = sweep kernels when generated with CSIM_CG_SWEEP\n"
         << "extern \"C\" int csim_sched_launch(const double* params, int B, double dt, long long stepFirst, long long nSteps,\n"
         << "                                 const int* probeEq, int nProbe, int outStride, double* wave, double* xio,\n"
         << "                                 long long* iters, unsigned* status, int* stepIters, unsigned char* fallback,\n"
-        << "                                 int* done, void* stream, int variant)\n{\n"
+        << "                                 int* done, int* violFlag, void* stream, int variant)\n{\n"
         << "    if (B <= 0) return 0;\n"
         << "    const unsigned waves = (unsigned)((B + 63) / 64);\n"
         << "    const bool rich = " << (haveRich ? "(variant == 2)" : "false") << ";\n"
         ;
     for (std::size_t k = 0; k < sweep.size(); ++k)
         src << "    if (variant == " << (10 + k) << ") { hipLaunchKernelGGL(csim_tran_sched_kernel_sweep" << k
-            << ", dim3(waves), dim3(64), 0, (hipStream_t)stream, params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status, stepIters, fallback, done); return (int)hipGetLastError(); }\n";
+            << ", dim3(waves), dim3(64), 0, (hipStream_t)stream, params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status, stepIters, fallback, done, violFlag); return (int)hipGetLastError(); }\n";
     if (haveRich)
         src << "    if (rich) {\n"
             << "        hipLaunchKernelGGL(csim_tran_sched_kernel_rich, dim3(waves), dim3(64), 0, (hipStream_t)stream,\n"
             << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
-            << "                           stepIters, fallback, done);\n"
+            << "                           stepIters, fallback, done, violFlag);\n"
             << "        return (int)hipGetLastError();\n    }\n";
     src << "    (void)rich;\n"
         << "    hipLaunchKernelGGL(csim_tran_sched_kernel, dim3(waves), dim3(64), 0, (hipStream_t)stream,\n"
         << "                       params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
-        << "                       stepIters, fallback, done);\n"
+        << "                       stepIters, fallback, done, violFlag);\n"
         << "    return (int)hipGetLastError();\n}\n";
     return src.str();
 }

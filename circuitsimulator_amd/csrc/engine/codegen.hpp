@@ -58,9 +58,21 @@ struct ScheduleSet {
     std::string str() const;
 };
 
+// Everything besides (circuit, schedules) that changes the emitted code.  There are NO environment
+// switches in the generator: options come from the caller (csim_codegen's command line; the engine's
+// JIT always uses the defaults) and are part of the hash that names a cached library.
+struct GeneratorOptions {
+    int barrierEvery = 3;        // scheduling barrier every n-th elimination column (0 = none)
+    std::vector<int> sweep;      // tuning aid: extra kernels csim_tran_sched_kernel_sweep<k> (see codegen.cpp)
+    bool set(const std::string& keyval);      // "barrier_every=3", "sweep=0,16,32"
+};
+
+// bumped whenever the emitted code or the launcher ABI of a generated library changes
+constexpr int kGeneratorRevision = 16;
+
 // identifies (topology, constants, schedule); names the generated library
 uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch);
-uint64_t scheduleHash(const csim_ir& ir, const ScheduleSet& set);
+uint64_t scheduleHash(const csim_ir& ir, const ScheduleSet& set, const GeneratorOptions& gopt = GeneratorOptions());
 
 struct CodegenStats {
     int nMul = 0, nFma = 0, nAddSub = 0, nRecip = 0, nCmp = 0, nDynU = 0, nLower = 0;
@@ -68,6 +80,7 @@ struct CodegenStats {
 
 // complete .hip translation unit: kernel + extern "C" launcher + metadata
 std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, const ScheduleSet& set,
-                                     const std::string& label, CodegenStats* stats);
+                                     const std::string& label, CodegenStats* stats,
+                                     const GeneratorOptions& gopt = GeneratorOptions());
 
 } // namespace csim

@@ -17,6 +17,7 @@
 #include "codegen.hpp"
 #include "csim.h"
 #include "engine_internal.hpp"
+#include "jit.hpp"
 #include "kernels.hpp"
 #include "netlist_internal.hpp"
 #include "plan.hpp"
@@ -137,6 +138,9 @@ void adoptScheduleTable(csim_engine* eng, void* lib)
     AltsFn fn = reinterpret_cast<AltsFn>(dlsym(lib, "csim_sched_alts"));
     eng->nKnownAlts = 0;
     if (eng->dKnownAlts) { (void)hipFree(eng->dKnownAlts); eng->dKnownAlts = nullptr; }
+    typedef int (*LanesFn)(void);
+    LanesFn lanesFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_group_lanes"));
+    eng->schedGroupLanes = lanesFn ? lanesFn() : 0;
     // DC operating-point kernel, present when the library was generated with "dc" schedules
     eng->schedDcLaunch = nullptr;
     if (AltsFn dcAlts = reinterpret_cast<AltsFn>(dlsym(lib, "csim_sched_dc_alts"))) {
@@ -152,6 +156,30 @@ void adoptScheduleTable(csim_engine* eng, void* lib)
     if (hipMalloc(reinterpret_cast<void**>(&eng->dKnownAlts), sizeof(int32_t) * (size_t)nAlts * n) != hipSuccess) return;
     if (hipMemcpy(eng->dKnownAlts, table, sizeof(int32_t) * (size_t)nAlts * n, hipMemcpyHostToDevice) != hipSuccess) return;
     eng->nKnownAlts = nAlts;
+}
+
+int envInt(const char* name, int dflt)
+{
+    const char* v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : dflt;
+}
+
+// the only place the engine reads the environment: once per csim_engine_create
+EngineConfig configFromEnvironment()
+{
+    EngineConfig c;
+    c.hybridRounds = std::max(0, envInt("CSIM_HYBRID_ROUNDS", c.hybridRounds));
+    c.hybridSteps = std::max(1, envInt("CSIM_HYBRID_STEPS", c.hybridSteps));
+    c.schedVariant = envInt("CSIM_SCHED_VARIANT", c.schedVariant);
+    c.lanesPerInstance = envInt("CSIM_LANES_PER_INSTANCE", c.lanesPerInstance);
+    c.autoJit = std::getenv("CSIM_AUTO_JIT") != nullptr;
+    c.jitDir = csim::jitDefaultDir();
+    const char* cc = std::getenv("CSIM_HIPCC");
+    c.hipcc = (cc && *cc) ? cc : "/opt/rocm/bin/hipcc";
+    c.jitTimeoutSec = std::max(1, envInt("CSIM_JIT_TIMEOUT", c.jitTimeoutSec));
+    c.jitDcAlts = std::max(0, std::min(8, envInt("CSIM_JIT_DC_ALTS", c.jitDcAlts)));
+    c.jitDcForce = std::getenv("CSIM_JIT_DC_FORCE") != nullptr;
+    return c;
 }
 
 // look for a generated kernel of this topology next to libcsim.so
@@ -174,7 +202,6 @@ void loadScheduledKernel(csim_engine* eng)
     eng->schedLaunch = launch;
     eng->schedInfo = infoFn ? infoFn() : "";
     adoptScheduleTable(eng, lib);
-    if (const char* v = std::getenv("CSIM_SCHED_VARIANT")) eng->schedVariant = std::atoi(v);
 }
 
 } // namespace
@@ -201,6 +228,7 @@ int csim_engine_create(const csim_netlist* nl, int32_t device, csim_engine** out
 
     auto* eng = new csim_engine();
     eng->device = device;
+    eng->cfg = configFromEnvironment();
     eng->cir = nl->cir;
     eng->cir.view();
     eng->plan = csim::buildAssemblyPlan(*eng->cir.view());
@@ -236,6 +264,8 @@ void csim_engine_destroy(csim_engine* eng)
     for (void* p : eng->owned) (void)hipFree(p);
     if (eng->dFallback) (void)hipFree(eng->dFallback);
     if (eng->dDone) (void)hipFree(eng->dDone);
+    if (eng->dViolFlag) (void)hipFree(eng->dViolFlag);
+    if (eng->hViolFlag) (void)hipHostFree(eng->hViolFlag);
     if (eng->dKnownAlts) (void)hipFree(eng->dKnownAlts);
     if (eng->dBigScratch) (void)hipFree(eng->dBigScratch);
     if (eng->schedLib) dlclose(eng->schedLib);
@@ -259,6 +289,29 @@ int csim_engine_set_kernel(csim_engine* eng, int32_t which)
     return CSIM_OK;
 }
 
+int csim_engine_set_option(csim_engine* eng, const char* key, const char* value)
+{
+    if (!eng || !key || !value) { setError("csim_engine_set_option: null argument"); return CSIM_ERR_ARG; }
+    const std::string k(key), v(value);
+    EngineConfig& c = eng->cfg;
+    const int iv = std::atoi(value);
+    if (k == "hybrid_rounds") c.hybridRounds = std::max(0, iv);
+    else if (k == "hybrid_steps") c.hybridSteps = std::max(1, iv);
+    else if (k == "sched_variant") c.schedVariant = iv;
+    else if (k == "lanes_per_instance") {
+        if (iv != 0 && iv != 1 && iv != 16) { setError("lanes_per_instance must be 0 (auto), 1 or 16"); return CSIM_ERR_ARG; }
+        c.lanesPerInstance = iv;
+    }
+    else if (k == "auto_jit") c.autoJit = iv != 0;
+    else if (k == "jit_dir") c.jitDir = v;
+    else if (k == "hipcc") c.hipcc = v;
+    else if (k == "jit_timeout") c.jitTimeoutSec = std::max(1, iv);
+    else if (k == "jit_dc_alts") c.jitDcAlts = std::max(0, std::min(8, iv));
+    else if (k == "jit_dc_force") c.jitDcForce = iv != 0;
+    else { setError("csim_engine_set_option: unknown option '" + k + "'"); return CSIM_ERR_ARG; }
+    return CSIM_OK;
+}
+
 int csim_mc_params_dev(csim_engine* eng, uint64_t seed, double sigma, int64_t b_first,
                        int32_t B, double* d_params, void* stream)
 {
@@ -270,9 +323,35 @@ int csim_mc_params_dev(csim_engine* eng, uint64_t seed, double sigma, int64_t b_
     return CSIM_OK;
 }
 
+// Did any instance leave the scheduled kernel unfinished?  One int comes back from the device; the
+// call waits for the stream here (the follow-up launches depend on the answer).
+static int readViolFlag(csim_engine* eng, hipStream_t hs, bool* any)
+{
+    HIPCHK(hipMemcpyAsync(eng->hViolFlag, eng->dViolFlag, sizeof(int32_t), hipMemcpyDeviceToHost, hs));
+    HIPCHK(hipStreamSynchronize(hs));
+    *any = *eng->hViolFlag != 0;
+    return CSIM_OK;
+}
+
+// which kernel of the generated library a launch of B instances uses (csim_sched_launch's `variant`):
+// 0 = lane per instance, 16 = sixteen lanes per instance, other values = tuning kernels
+static int schedVariantFor(const csim_engine* eng, int32_t B)
+{
+    if (eng->cfg.schedVariant != 0) return eng->cfg.schedVariant;
+    if (eng->cfg.lanesPerInstance == 16) return 16;
+    if (eng->cfg.lanesPerInstance == 1) return 0;
+    // auto: sixteen lanes per instance while the batch cannot give every SIMD a wave of its own
+    // (lane-per-instance needs 64 instances per wave and the chip has 1024 SIMDs)
+    return (eng->schedGroupLanes == 16 && (int64_t)B * 16 <= 64 * 1024 * 2) ? 16 : 0;
+}
+
 // per-instance fallback mask and progress counters of the scheduled kernels
 static int ensureFallbackBuffers(csim_engine* eng, int32_t B)
 {
+    if (!eng->dViolFlag) {
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dViolFlag), sizeof(int32_t)));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&eng->hViolFlag), sizeof(int32_t), hipHostMallocDefault));
+    }
     if (eng->fallbackCap >= B) return CSIM_OK;
     if (eng->dFallback) HIPCHK(hipFree(eng->dFallback));
     if (eng->dDone) HIPCHK(hipFree(eng->dDone));
@@ -307,11 +386,14 @@ int csim_dc_batch_dev(csim_engine* eng, const double* d_params, int32_t B, doubl
         const int rc = ensureFallbackBuffers(eng, B);
         if (rc) return rc;
         HIPCHK(hipMemsetAsync(eng->dFallback, 0, (size_t)B, hs));
-        if (eng->schedDcLaunch(d_params, B, d_x, d_iters, d_status, eng->dFallback, stream) != 0) {
+        HIPCHK(hipMemsetAsync(eng->dViolFlag, 0, sizeof(int32_t), hs));
+        if (eng->schedDcLaunch(d_params, B, d_x, d_iters, d_status, eng->dFallback, eng->dViolFlag, stream) != 0) {
             setError("scheduled DC kernel launch failed");
             return CSIM_ERR_HIP;
         }
-        HIPCHK(csim::launchDcGeneral(eng->gpDc, d_params, B, d_x, d_iters, d_status, hs, eng->dFallback));
+        bool any = false;
+        if (const int frc = readViolFlag(eng, hs, &any)) return frc;
+        if (any) HIPCHK(csim::launchDcGeneral(eng->gpDc, d_params, B, d_x, d_iters, d_status, hs, eng->dFallback));
         return CSIM_OK;
     }
     HIPCHK(csim::launchDcGeneral(eng->gpDc, d_params, B, d_x, d_iters, d_status, hs));
@@ -355,36 +437,37 @@ int csim_tran_batch_dev(csim_engine* eng, const double* d_params, int32_t B, dou
         }
         return CSIM_OK;
     };
-    if (!(eng->schedLaunch && eng->kernelChoice != 1)) return general(nullptr, 0);
+    // n_steps == 0 (a run shorter than one step is legal upstream and yields the t = 0 row only): the
+    // general kernel writes that row; the hybrid sequence below would return before it
+    if (!(eng->schedLaunch && eng->kernelChoice != 1) || n_steps == 0) return general(nullptr, 0);
 
-    // Fast path with hybrid stepping.  The generated lane-per-instance kernel advances every
-    // instance until the launch is complete or one of its pivot checks fails (no recorded
-    // schedule fits that factorisation); it checkpoints the state at the start of the failing
-    // step and records per-instance progress in dDone.  The general kernel then advances the
-    // unfinished instances by a couple of steps with run-time pivoting and hands them back.
-    // Blocks/lanes with nothing left exit at once, so the extra launches cost microseconds.
+    // Fast path with hybrid stepping.  The generated kernel advances every instance until the launch
+    // is complete or one of its checks fails (no recorded schedule fits that factorisation, or the
+    // Newton iteration of a step ends at its cap); it keeps the state at the start of the failing
+    // step and records per-instance progress in dDone.  One int tells the host whether any instance
+    // is unfinished: if none is (the usual case) the call ends after ONE launch.  Otherwise the
+    // general kernel advances the unfinished instances with run-time pivoting until a whole step
+    // ran on recorded sequences again and hands them back, for at most cfg.hybridRounds rounds.
     {
         const int rc = ensureFallbackBuffers(eng, B);
         if (rc) return rc;
     }
     HIPCHK(hipMemsetAsync(eng->dFallback, 0, (size_t)B, hs));
     HIPCHK(hipMemsetAsync(eng->dDone, 0, sizeof(int32_t) * (size_t)B, hs));
-    auto scheduled = [&]() -> int {
+    auto scheduled = [&](bool* anyUnfinished) -> int {
+        HIPCHK(hipMemsetAsync(eng->dViolFlag, 0, sizeof(int32_t), hs));
         const int lrc = eng->schedLaunch(d_params, B, tstep, step_first, n_steps, dProbe, np, os, d_wave, d_x,
                                          reinterpret_cast<long long*>(d_iters), d_status, d_step_iters,
-                                         eng->dFallback, eng->dDone, stream, eng->schedVariant);
+                                         eng->dFallback, eng->dDone, eng->dViolFlag, stream, schedVariantFor(eng, B));
         if (lrc != 0) { setError(std::string("scheduled kernel launch: ") + hipGetErrorString((hipError_t)lrc)); return CSIM_ERR_HIP; }
-        return CSIM_OK;
+        return readViolFlag(eng, hs, anyUnfinished);
     };
-    int rc = scheduled();
-    if (rc) return rc;
-    // one round per violation episode; the general kernel keeps an instance until a whole step ran on
-    // recorded sequences again (small kernels) or for at most handBackAfter steps
-    const int rounds = std::getenv("CSIM_HYBRID_ROUNDS") ? std::atoi(std::getenv("CSIM_HYBRID_ROUNDS")) : 4;
-    const int handBackAfter = std::getenv("CSIM_HYBRID_STEPS") ? std::atoi(std::getenv("CSIM_HYBRID_STEPS")) : 64;
-    for (int r = 0; r < rounds; ++r) {
-        if ((rc = general(eng->dDone, handBackAfter, true))) return rc;
-        if ((rc = scheduled())) return rc;
+    bool unfinished = false;
+    int rc = scheduled(&unfinished);
+    if (rc || !unfinished) return rc;
+    for (int r = 0; r < eng->cfg.hybridRounds; ++r) {
+        if ((rc = general(eng->dDone, eng->cfg.hybridSteps, true))) return rc;
+        if ((rc = scheduled(&unfinished)) || !unfinished) return rc;
     }
     return general(eng->dDone, 2147483647);      // whatever is still unfinished runs to the end of the launch
 }
@@ -515,7 +598,7 @@ int csim_tran_batch(csim_engine* eng, const double* params, int32_t B, double ts
     // CSIM_AUTO_JIT=1: a circuit without a prebuilt kernel is specialised on first use (what bench.py does
     // explicitly), so that callers of the reference-shaped API get the fast path without new code.  Worth it
     // for long runs only (the compile takes seconds); a failure leaves the general kernel in place.
-    if (!eng->schedLaunch && eng->kernelChoice != 1 && nSteps >= 1000 && std::getenv("CSIM_AUTO_JIT") != nullptr) {
+    if (!eng->schedLaunch && eng->kernelChoice != 1 && nSteps >= 1000 && eng->cfg.autoJit) {
         if (csim_engine_jit_scheduled(eng, dParams.as<double>(), B, tstep, nSteps < 200 ? nSteps : 200) != CSIM_OK)
             std::fprintf(stderr, "csim: CSIM_AUTO_JIT: %s -- staying on the general kernel\n", csim_last_error());
     }
@@ -727,6 +810,94 @@ int csim_record_pivot_schedule(csim_engine* eng, const double* d_params, int32_t
     return CSIM_OK;
 }
 
+// generate + compile + load the kernels of `sch` for this engine's circuit (cached by hash)
+static int buildAndLoadScheduled(csim_engine* eng, const csim::ScheduleSet& sch)
+{
+    const csim_ir* ir = eng->cir.view();
+    const int N = ir->n_unknowns;
+    const unsigned long long topo = csim::scheduleHash(*ir, csim::PivotSchedule::identity(N));
+    const unsigned long long full = csim::scheduleHash(*ir, sch);
+    const std::string dir = eng->cfg.jitDir;
+    {
+        const std::string why = csim::jitPrepareDir(dir);
+        if (!why.empty()) { setError("JIT cache: " + why); return CSIM_ERR_IO; }
+    }
+    char stem[96];
+    std::snprintf(stem, sizeof stem, "/libcsim_sched_%016llx_%016llx", topo, full);
+    const std::string lib = dir + stem + ".so", hip = dir + stem + ".hip", log = dir + stem + ".log";
+
+    typedef unsigned long long (*HashFn)(void);
+    typedef const char* (*InfoFn)(void);
+    // a library is loaded only if it is a regular file of the calling user inside the private directory,
+    // and kept only if it reports the hash of exactly this (circuit, schedules, generator options, revision)
+    auto openChecked = [&](const std::string& path) -> void* {
+        if (!csim::jitFileTrusted(path)) return nullptr;
+        void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) return nullptr;
+        HashFn topoFn = reinterpret_cast<HashFn>(dlsym(h, "csim_sched_topology"));
+        HashFn fullFn = reinterpret_cast<HashFn>(dlsym(h, "csim_sched_hash"));
+        if (!topoFn || !fullFn || topoFn() != topo || fullFn() != full || !dlsym(h, "csim_sched_launch")) { dlclose(h); return nullptr; }
+        return h;
+    };
+    void* handle = openChecked(lib);
+    if (!handle) {
+        const std::string src = csim::generateTranKernelSource(*ir, eng->plan, sch, "jit", nullptr);
+        if (src.empty()) { setError("circuit too large for a scheduled kernel (iterate does not fit LDS)"); return CSIM_ERR_UNSUPPORTED; }
+        // several ranks may specialise the same circuit at once: private temporaries, atomic rename
+        const std::string tag = "." + std::to_string((long long)getpid());
+        const std::string hipTmp = hip + tag, libTmp = lib + tag, logTmp = log + tag;
+        FILE* f = std::fopen(hipTmp.c_str(), "w");
+        if (!f) { setError("cannot write " + hipTmp); return CSIM_ERR_IO; }
+        std::fwrite(src.data(), 1, src.size(), f);
+        std::fclose(f);
+        const std::string why = csim::jitRun({eng->cfg.hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-shared",
+                                              "-x", "hip", hipTmp, "-o", libTmp}, logTmp, eng->cfg.jitTimeoutSec);
+        if (!why.empty()) { (void)std::remove(libTmp.c_str()); setError("JIT compile: " + why); return CSIM_ERR_UNSUPPORTED; }
+        if (std::rename(libTmp.c_str(), lib.c_str()) != 0) { setError("cannot move " + libTmp + " into place"); return CSIM_ERR_IO; }
+        (void)std::rename(hipTmp.c_str(), hip.c_str());
+        handle = openChecked(lib);
+        if (!handle) { setError("generated library " + lib + " could not be loaded or does not match the circuit"); return CSIM_ERR_IO; }
+    }
+    InfoFn infoFn = reinterpret_cast<InfoFn>(dlsym(handle, "csim_sched_info"));
+    if (eng->schedLib) dlclose(eng->schedLib);
+    eng->schedLib = handle;
+    eng->schedLaunch = reinterpret_cast<csim_engine::SchedLaunchFn>(dlsym(handle, "csim_sched_launch"));
+    eng->schedInfo = infoFn ? infoFn() : "";
+    adoptScheduleTable(eng, handle);
+    return CSIM_OK;
+}
+
+int csim_engine_jit_with_schedules(csim_engine* eng, const int32_t* pivot_pos, int32_t n_alts,
+                                   const int32_t* dc_pivot_pos, int32_t n_dc_alts)
+{
+    if (!eng || !pivot_pos || n_alts <= 0 || n_alts > 8 || n_dc_alts < 0 || n_dc_alts > 8 || (n_dc_alts > 0 && !dc_pivot_pos)) {
+        setError("csim_engine_jit_with_schedules: bad argument");
+        return CSIM_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(eng->device));
+    const int N = eng->cir.view()->n_unknowns;
+    csim::ScheduleSet sch;
+    auto take = [&](const int32_t* pos, int n, std::vector<csim::PivotSchedule>& dst) -> bool {
+        for (int a = 0; a < n; ++a) {
+            csim::PivotSchedule one = csim::PivotSchedule::identity(N);
+            for (int k = 0; k < N; ++k) {
+                const int p = pos[(size_t)a * N + k];
+                if (p < k || p >= N) return false;
+                one.pivotPos[(size_t)k] = p;
+            }
+            bool dup = false;
+            for (const csim::PivotSchedule& o : dst) dup = dup || o.pivotPos == one.pivotPos;
+            if (!dup) dst.push_back(one);
+        }
+        return true;
+    };
+    if (!take(pivot_pos, n_alts, sch.alts) || !take(dc_pivot_pos, n_dc_alts, sch.dcAlts)) {
+        setError("csim_engine_jit_with_schedules: pivot position out of range (need k <= pos < N)");
+        return CSIM_ERR_ARG;
+    }
+    return buildAndLoadScheduled(eng, sch);
+}
+
 int csim_engine_jit_scheduled(csim_engine* eng, const double* d_params, int32_t B, double tstep, int64_t plan_steps)
 {
     if (!eng || !d_params || B <= 0 || !(tstep > 0.0) || plan_steps <= 0) { setError("csim_engine_jit_scheduled: bad argument"); return CSIM_ERR_ARG; }
@@ -753,8 +924,8 @@ int csim_engine_jit_scheduled(csim_engine* eng, const double* d_params, int32_t 
                                       &instStatus);
         if (rc) return rc;
         // An instance whose Newton iterations do not converge (or that met a failed factorisation) is not a
-        // pattern worth specialising for: its trajectory is chaotic, only the bit-faithful general kernel
-        // reproduces it, and that is where its schedule violations send it.  Instance 0 always counts.
+        // pattern worth specialising for: its steps are redone by the general kernel anyway (the generated
+        // kernel hands over every step that ends at the NR cap).  Instance 0 always counts.
         const uint32_t trouble = CSIM_ST_TRAN_NONFINITE | CSIM_ST_TRAN_NONCONV | CSIM_ST_LU_TINY_PIVOT |
                                  CSIM_ST_DC_NONCONV | CSIM_ST_DC_NONFINITE;
         if (inst != 0 && (instStatus & trouble)) continue;
@@ -776,12 +947,11 @@ int csim_engine_jit_scheduled(csim_engine* eng, const double* d_params, int32_t 
     // The DC operating point of Newton circuits gets its own schedules (planned on the same instance),
     // but only when a few sequences cover that instance's whole ramp: a circuit that walks through many
     // (buffer.sp: 10) would fail its checks in most instances and pay for both kernels.
-    // CSIM_JIT_DC_ALTS = limit (default 4, at most 8); CSIM_JIT_DC_FORCE=1 keeps a partial cover (tests).
+    // cfg.jitDcAlts = limit (default 4, at most 8); cfg.jitDcForce keeps a partial cover (tests).
     if (ir->has_nonlinear && !eng->big) {
         const int planMax = 8;
-        int limit = 4;
-        if (const char* v = std::getenv("CSIM_JIT_DC_ALTS")) limit = std::max(0, std::min(planMax, std::atoi(v)));
-        const bool force = std::getenv("CSIM_JIT_DC_FORCE") != nullptr;
+        const int limit = eng->cfg.jitDcAlts;
+        const bool force = eng->cfg.jitDcForce;
         std::vector<int32_t> dpos((size_t)planMax * N);
         int32_t nDc = 0;
         int64_t dcOther = 0;
@@ -796,48 +966,7 @@ int csim_engine_jit_scheduled(csim_engine* eng, const double* d_params, int32_t 
             }
         }
     }
-
-    const unsigned long long topo = csim::scheduleHash(*ir, csim::PivotSchedule::identity(N));
-    const unsigned long long full = csim::scheduleHash(*ir, sch);
-    const char* dirEnv = std::getenv("CSIM_JIT_DIR");
-    const std::string dir = dirEnv ? dirEnv : "/tmp/csim_jit";
-    char stem[96];
-    std::snprintf(stem, sizeof stem, "/libcsim_sched_%016llx_%016llx", topo, full);
-    const std::string lib = dir + stem + ".so", hip = dir + stem + ".hip", log = dir + stem + ".log";
-
-    void* handle = dlopen(lib.c_str(), RTLD_NOW | RTLD_LOCAL);
-    if (!handle) {
-        if (std::system(("mkdir -p '" + dir + "'").c_str()) != 0) { setError("cannot create " + dir); return CSIM_ERR_IO; }
-        const std::string src = csim::generateTranKernelSource(*ir, eng->plan, sch, "jit", nullptr);
-        if (src.empty()) { setError("circuit too large for a scheduled kernel (iterate does not fit LDS)"); return CSIM_ERR_UNSUPPORTED; }
-        // several ranks may specialise the same circuit at once: private temporaries, atomic rename
-        const std::string tag = "." + std::to_string((long long)getpid());
-        const std::string hipTmp = hip + tag, libTmp = lib + tag;
-        FILE* f = std::fopen(hipTmp.c_str(), "w");
-        if (!f) { setError("cannot write " + hipTmp); return CSIM_ERR_IO; }
-        std::fwrite(src.data(), 1, src.size(), f);
-        std::fclose(f);
-        const char* ccEnv = std::getenv("CSIM_HIPCC");
-        const std::string cc = ccEnv ? ccEnv : "/opt/rocm/bin/hipcc";
-        const std::string cmd = cc + " -O3 -std=c++17 -fPIC --offload-arch=gfx950 -shared -x hip '" + hipTmp + "' -o '" +
-                                libTmp + "' > '" + log + tag + "' 2>&1 && mv '" + libTmp + "' '" + lib + "' && mv '" +
-                                hipTmp + "' '" + hip + "'";
-        if (std::system(cmd.c_str()) != 0) { setError("hipcc failed, see " + log + tag); return CSIM_ERR_UNSUPPORTED; }
-        handle = dlopen(lib.c_str(), RTLD_NOW | RTLD_LOCAL);
-        if (!handle) { setError(std::string("dlopen: ") + dlerror()); return CSIM_ERR_IO; }
-    }
-    typedef unsigned long long (*HashFn)(void);
-    typedef const char* (*InfoFn)(void);
-    HashFn topoFn = reinterpret_cast<HashFn>(dlsym(handle, "csim_sched_topology"));
-    InfoFn infoFn = reinterpret_cast<InfoFn>(dlsym(handle, "csim_sched_info"));
-    auto launch = reinterpret_cast<csim_engine::SchedLaunchFn>(dlsym(handle, "csim_sched_launch"));
-    if (!topoFn || !launch || topoFn() != topo) { dlclose(handle); setError("generated library does not match the circuit"); return CSIM_ERR_UNSUPPORTED; }
-    if (eng->schedLib) dlclose(eng->schedLib);
-    eng->schedLib = handle;
-    eng->schedLaunch = launch;
-    eng->schedInfo = infoFn ? infoFn() : "";
-    adoptScheduleTable(eng, handle);
-    return CSIM_OK;
+    return buildAndLoadScheduled(eng, sch);
 }
 
 int csim_lu_decompose_batch(int32_t device, int32_t n, int32_t B, const double* A, double* LU,

@@ -9,10 +9,25 @@
 #include "device_common.hpp"
 #include "plan.hpp"
 
+// Run-time options of one engine.  The environment is read ONCE, in csim_engine_create (defaults of
+// the fields below); csim_engine_set_option changes them afterwards.  Nothing on a hot path calls getenv.
+struct EngineConfig {
+    int hybridRounds = 4;        // hybrid_rounds  / CSIM_HYBRID_ROUNDS: hand-back rounds per transient call
+    int hybridSteps = 64;        // hybrid_steps   / CSIM_HYBRID_STEPS: most steps the general kernel keeps an instance per round
+    int schedVariant = 0;        // sched_variant  / CSIM_SCHED_VARIANT: 0 auto, 2 rich, 10+k sweep kernels (tuning aid)
+    int lanesPerInstance = 0;    // lanes_per_instance / CSIM_LANES_PER_INSTANCE: 0 auto (by batch size), 1 or 16
+    bool autoJit = false;        // auto_jit       / CSIM_AUTO_JIT: host API specialises a new circuit on first use
+    std::string jitDir;          // jit_dir        / CSIM_JIT_DIR (default: private per-user directory, jit.hpp)
+    std::string hipcc;           // hipcc          / CSIM_HIPCC
+    int jitTimeoutSec = 600;     // jit_timeout    / CSIM_JIT_TIMEOUT: wall-clock limit of one compile
+    int jitDcAlts = 4;           // jit_dc_alts    / CSIM_JIT_DC_ALTS: most DC sequences a JIT kernel may carry
+    bool jitDcForce = false;     // jit_dc_force   / CSIM_JIT_DC_FORCE: keep a partial DC cover (tests)
+};
+
 struct csim_engine {
     int device = 0;
     int kernelChoice = 0;                  // 0 auto, 1 general, 2 scheduled
-    int schedVariant = 0;                  // 0 by batch size, 1 lean, 2 rich (CSIM_SCHED_VARIANT)
+    EngineConfig cfg;
     csim::CircuitIR cir;                   // private copy of the flattened circuit
     csim::AssemblyPlan plan;
 
@@ -29,18 +44,21 @@ struct csim_engine {
 
     // circuit-specialised transient kernel (side library libcsim_sched_<topology>.so)
     typedef int (*SchedLaunchFn)(const double*, int, double, long long, long long, const int*, int, int,
-                                 double*, double*, long long*, unsigned*, int*, unsigned char*, int*, void*, int);
+                                 double*, double*, long long*, unsigned*, int*, unsigned char*, int*, int*, void*, int);
     // DC operating point of the same library (nullptr: the library carries no DC schedule)
-    typedef int (*SchedDcLaunchFn)(const double*, int, double*, int*, unsigned*, unsigned char*, void*);
+    typedef int (*SchedDcLaunchFn)(const double*, int, double*, int*, unsigned*, unsigned char*, int*, void*);
     void* schedLib = nullptr;
     SchedLaunchFn schedLaunch = nullptr;
     SchedDcLaunchFn schedDcLaunch = nullptr;
     std::string schedInfo;
+    int schedGroupLanes = 0;               // 16 when the library also carries the sixteen-lanes-per-instance kernel
     int32_t* dKnownAlts = nullptr;         // [nKnownAlts][N] pivot sequences the loaded kernel carries
     int nKnownAlts = 0;
     unsigned char* dFallback = nullptr;    // per-instance "a schedule check failed in this launch" mask
     int32_t* dDone = nullptr;              // per-instance steps of the current launch already completed
     int fallbackCap = 0;
+    int32_t* dViolFlag = nullptr;          // one int: "some instance left the scheduled kernel unfinished"
+    int32_t* hViolFlag = nullptr;          // its pinned host mirror
 
     // large circuits (N > 63): dense scratch matrices in global memory, one per instance
     bool big = false;

@@ -180,6 +180,7 @@ k_tran_general(GenPlan pl, const double* __restrict__ params, int B, double dt,
     for (long long s = d0 + 1; s <= sEnd && !aborted; ++s) {
         sLast = s;
         bool stepKnown = curPiv != nullptr;     // every factorisation of this step on a known sequence?
+        bool stepConverged = false;             // a step that ends at the NR cap is not handed back either
         const long long gstep = stepFirst + s;
         const double tNow = (double)(int)gstep * dt;                    // :256
         terms_step_tran(pl, Pv, T, xp, tNow, lane);
@@ -202,7 +203,7 @@ k_tran_general(GenPlan pl, const double* __restrict__ params, int B, double dt,
             const double err = norm_in_order(xn - xo, sc, N, lane);     // :366
             if (lane < N) xs[lane] = xn;                                // :367
             wave_sync();
-            if (err < K.tran_tol) break;                                // :369-371
+            if (err < K.tran_tol) { stepConverged = true; break; }      // :369-371
             if (iter == K.tran_max_iters - 1) st |= CSIM_ST_TRAN_NONCONV;   // :372-376
         }
         itTotal += it;
@@ -213,7 +214,7 @@ k_tran_general(GenPlan pl, const double* __restrict__ params, int B, double dt,
         if (wave && (gstep % outStride) == 0)                           // :419
             for (int q = lane; q < nProbe; q += 64)
                 wave[((gstep / outStride) * nProbe + q) * (int64_t)B + b] = xs[probeEq[q]];
-        if (stepKnown) break;                   // back on a recorded schedule: hand the instance back
+        if (stepKnown && stepConverged) break;  // back on a recorded schedule and converging: hand the instance back
     }
 
     if (lane < N) xio[(int64_t)lane * B + b] = xs[lane];

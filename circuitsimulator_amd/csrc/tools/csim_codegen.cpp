@@ -2,6 +2,8 @@
 //
 //   csim_codegen <netlist.sp> <schedule-file|-> <out.hip>      writes HIP source, prints the hash
 //   csim_codegen --hash <netlist.sp> <schedule-file|->          prints the hash only
+//   csim_codegen --opt key=value ... (before the other arguments): generator options
+//     (barrier_every=3, sweep=0,16,32 -- tuning aids, part of the library's hash)
 //
 // The schedule file holds the partial-pivot row swaps of the transient
 // factorisation as "column:row,column:row,..." ('-' = no swaps).  It is
@@ -31,6 +33,12 @@ static std::string readSchedule(const std::string& path)
 
 int main(int argc, char** argv)
 {
+    csim::GeneratorOptions gopt;
+    while (argc >= 3 && std::string(argv[1]) == "--opt") {
+        if (!gopt.set(argv[2])) { std::cerr << "unknown generator option " << argv[2] << "\n"; return 1; }
+        argv += 2;
+        argc -= 2;
+    }
     const bool hashOnly = argc >= 2 && std::string(argv[1]) == "--hash";
     if ((hashOnly && argc != 4) || (!hashOnly && argc != 4)) {
         std::cerr << "usage: csim_codegen <netlist.sp> <schedule|-> <out.hip>\n"
@@ -52,7 +60,7 @@ int main(int argc, char** argv)
         std::cerr << "bad schedule\n";
         return 2;
     }
-    const unsigned long long h = csim::scheduleHash(*ir, sch);
+    const unsigned long long h = csim::scheduleHash(*ir, sch, gopt);
     // the library is NAMED by the topology hash (what an engine can compute before it
     // knows any schedule); the full hash is embedded for diagnostics
     const unsigned long long topo = csim::scheduleHash(*ir, csim::PivotSchedule::identity(ir->n_unknowns));
@@ -62,7 +70,7 @@ int main(int argc, char** argv)
     const std::size_t slash = label.find_last_of('/');
     if (slash != std::string::npos) label = label.substr(slash + 1);
     csim::CodegenStats st;
-    const std::string src = csim::generateTranKernelSource(*ir, ap, sch, label, &st);
+    const std::string src = csim::generateTranKernelSource(*ir, ap, sch, label, &st, gopt);
     std::ofstream out(argv[3]);
     if (!out) { std::cerr << "cannot write " << argv[3] << "\n"; return 2; }
     out << src;

@@ -140,6 +140,10 @@ class Engine:
     def set_kernel(self, which):
         capi.check(capi.lib().csim_engine_set_kernel(self._h, {"auto": 0, "general": 1, "scheduled": 2}[which]))
 
+    def set_option(self, key, value):
+        """csim_engine_set_option: hybrid_rounds, hybrid_steps, lanes_per_instance, jit_dir, ... (include/csim.h)"""
+        capi.check(capi.lib().csim_engine_set_option(self._h, str(key).encode(), str(value).encode()))
+
     # -- device-pointer forms (torch tensors on cuda:<device>, slot-major) ----
     def _dev(self):
         return "cuda:%d" % self.device
@@ -234,6 +238,26 @@ class Engine:
         tstep = self.netlist.tstep if tstep is None else tstep
         capi.check(capi.lib().csim_engine_jit_scheduled(self._h, params.data_ptr(), params.shape[1], float(tstep),
                                                         int(plan_steps)))
+
+    @staticmethod
+    def _positions(schedules, N):
+        """["0:21,8:22", "-", ...] -> int32 [n][N] pivot row positions"""
+        pos = np.tile(np.arange(N, dtype=np.int32), (len(schedules), 1))
+        for a, text in enumerate(schedules):
+            for item in text.replace("-", "").split(","):
+                if item.strip():
+                    k, p = item.split(":")
+                    pos[a, int(k)] = int(p)
+        return np.ascontiguousarray(pos)
+
+    def jit_with_schedules(self, schedules, dc_schedules=()):
+        """Generate + hipcc + load the kernels for explicit pivot schedules ("k:p,k:p" strings as
+        returned by record_pivot_schedules / record_dc_pivot_schedules)."""
+        pos = self._positions(list(schedules), self.N)
+        dpos = self._positions(list(dc_schedules), self.N) if len(dc_schedules) else None
+        capi.check(capi.lib().csim_engine_jit_with_schedules(
+            self._h, pos.ctypes.data, pos.shape[0], dpos.ctypes.data if dpos is not None else None,
+            dpos.shape[0] if dpos is not None else 0))
 
     def record_pivot_schedule(self, params, instance=0, tstep=None, n_steps=200):
         """Planner: pivot row position per column of the first transient factorisation of one

@@ -112,6 +112,24 @@ const char* csim_engine_tran_kernel(const csim_engine* eng);
 /* force a kernel family: 0 = auto, 1 = general only, 2 = scheduled required  */
 int  csim_engine_set_kernel(csim_engine* eng, int32_t which);
 
+/* Run-time options of one engine, as text.  The environment variable named with each key is read
+ * ONCE, in csim_engine_create, as the key's default; nothing on a hot path reads the environment.
+ *   hybrid_rounds (CSIM_HYBRID_ROUNDS, 4)   hand-back rounds between the scheduled and the general
+ *                                           kernel per transient call
+ *   hybrid_steps  (CSIM_HYBRID_STEPS, 64)   most steps the general kernel keeps an instance per round
+ *   lanes_per_instance (CSIM_LANES_PER_INSTANCE, 0)  scheduled transient kernel: 1 = lane per instance,
+ *                                           16 = sixteen lanes per instance, 0 = chosen by batch size
+ *   sched_variant (CSIM_SCHED_VARIANT, 0)   tuning kernels of a generated library (2 rich, 10+k sweep)
+ *   auto_jit (CSIM_AUTO_JIT, off)           csim_tran_batch specialises a new circuit on first use
+ *   jit_dir (CSIM_JIT_DIR; default $XDG_CACHE_HOME/csim_jit or /tmp/csim_jit.<uid>)  JIT cache: created
+ *                                           0700; must be a real directory of the calling user, not
+ *                                           writable by group/others; only regular files of the calling
+ *                                           user are ever loaded from it
+ *   hipcc (CSIM_HIPCC, /opt/rocm/bin/hipcc), jit_timeout (CSIM_JIT_TIMEOUT, 600 s)
+ *   jit_dc_alts (CSIM_JIT_DC_ALTS, 4), jit_dc_force (CSIM_JIT_DC_FORCE, off)  DC schedules kept by the JIT
+ * Unknown key or bad value: CSIM_ERR_ARG.                                                        */
+int  csim_engine_set_option(csim_engine* eng, const char* key, const char* value);
+
 /* Monte-Carlo parameter table on the device: instance b_first+i of the global
  * batch -> column i.  Instance 0 is the nominal circuit.  Counter-based:
  * any shard regenerates any instance from (seed, instance, slot).            */
@@ -172,12 +190,21 @@ int  csim_lu_solve_batch(int32_t device, int32_t n, int32_t B, const double* A,
  * records the pivot schedule of instance 0 of d_params with the general kernel
  * (plan_steps transient steps), generates the lane-per-instance kernel, compiles it
  * (up to 4 distinct sequences seen while planning become alternatives), compiles it
- * with hipcc (--offload-arch=gfx950; $CSIM_HIPCC overrides the compiler path) into
- * $CSIM_JIT_DIR (default /tmp/csim_jit) and loads it.  A cached library of the same
- * (topology, constants, schedule) hash is reused.  After CSIM_OK,
- * csim_engine_tran_kernel() reports "scheduled".                                  */
+ * with hipcc (--offload-arch=gfx950; a child process started from an argument vector,
+ * no shell, killed after jit_timeout seconds) into the private JIT cache directory
+ * (csim_engine_set_option) and loads it.  A cached library is reused only if it is the
+ * caller's own regular file and reports the hash of exactly this (topology, constants,
+ * schedules, generator revision).  After CSIM_OK, csim_engine_tran_kernel() reports
+ * "scheduled".                                                                      */
 int  csim_engine_jit_scheduled(csim_engine* eng, const double* d_params /*[P][B]*/, int32_t B,
                                double tstep, int64_t plan_steps);
+/* The build half of the above for schedules the caller already has (from the planner
+ * entry points below, or from a schedule file): pivot_pos [n_alts][N] transient
+ * sequences, most frequent first (1..8); dc_pivot_pos [n_dc_alts][N] sequences of the DC
+ * operating point (0..8; 0 = no DC kernel).  Schedules decide speed only: every
+ * factorisation re-verifies the sequence it uses.                                   */
+int  csim_engine_jit_with_schedules(csim_engine* eng, const int32_t* pivot_pos, int32_t n_alts,
+                                    const int32_t* dc_pivot_pos, int32_t n_dc_alts);
 
 /* Batched Solver::luDecompose (include/solver.hpp:30-80): LU [B][n][n] holds U on
  * and above the diagonal and the multipliers below it, perm [B][n] the row

@@ -55,7 +55,7 @@ def has_gpu():
         return False
 
 
-def rel_err(a, ref, n_node_eq):
+def rel_err(a, ref):
     """|a-ref| / max(|ref|, floor), floor = 1e-6 (V for node voltages, A for branch currents).
 
     A pure relative test is meaningless on near-zero entries.  Branch

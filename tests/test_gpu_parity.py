@@ -73,7 +73,7 @@ def test_dc_nominal_vs_anchors_and_oracle(name, engines, anchors):
     assert list(it) == [a["dc_iters"]] * 3 == [ito] * 3
     assert list(st) == [sto] * 3
     assert np.array_equal(x[0], x[1]) and np.array_equal(x[0], x[2])
-    assert rel_err(x[0], xo, nl.n_node_eq).max() < TOL
+    assert rel_err(x[0], xo).max() < TOL
     for eqname, s in a["dc_x"].items():           # golden 17-digit anchors
         i = nl.eq_names.index(eqname)
         floor = 1e-6
@@ -92,7 +92,7 @@ def test_dc_mc_batch_vs_oracle(name, engines, torch_mod):
     for b in (0, 1, 2, 3, 17, B - 1):
         xo, ito, sto = _orc().dc(nl.ir_ptr, nl.n_unknowns, ph, b)
         assert it[b] == ito and st[b] == sto, (b, it[b], ito, st[b], sto)
-        assert rel_err(x[:, b], xo, nl.n_node_eq).max() < TOL, b
+        assert rel_err(x[:, b], xo).max() < TOL, b
 
 
 def test_mc_params_device_equals_host_bitwise(engines, torch_mod):
@@ -115,7 +115,7 @@ def test_buffer_transient_as_shipped_full_waveform(engines, torch_mod, anchors):
     assert (r["status"][0] & NOFB) == o["status"]
     wave = np.transpose(r["wave"], (2, 0, 1))          # [B][rows][N]
     assert np.array_equal(wave[0], wave[1])
-    assert rel_err(wave[0], o["rows"][:, 1:], nl.n_node_eq).max() < TOL
+    assert rel_err(wave[0], o["rows"][:, 1:]).max() < TOL
     for eqname, s in anchors["buffer"]["last_row"].items():
         i = nl.eq_names.index(eqname)
         floor = 1e-6
@@ -133,7 +133,7 @@ def test_buffer_10k_steps_batch1_config(engines, torch_mod, anchors):
     o = _orc().tran(nl.ir_ptr, nl.n_unknowns, nl.nominal_params, 0, tstep, tstop, want_step_iters=True)
     assert r["iters"][0] == anchors["buffer"]["tran10k_iters"] == o["iters"]
     assert np.array_equal(r["step_iters"][:, 0], o["step_iters"])
-    assert rel_err(r["wave"][:, :, 0], o["rows"][:, 1:], nl.n_node_eq).max() < TOL
+    assert rel_err(r["wave"][:, :, 0], o["rows"][:, 1:]).max() < TOL
 
 
 def test_dbmixer_mc_transient_vs_oracle(engines, torch_mod):
@@ -147,7 +147,7 @@ def test_dbmixer_mc_transient_vs_oracle(engines, torch_mod):
         assert r["iters"][b] == o["iters"], b
         assert np.array_equal(r["step_iters"][:, b], o["step_iters"]), b
         assert (r["status"][b] & NOFB) == o["status"], b
-        assert rel_err(r["x"][:, b], o["x_final"], nl.n_node_eq).max() < TOL, b
+        assert rel_err(r["x"][:, b], o["x_final"]).max() < TOL, b
         ref = o["rows"][::100, 1:][:, nl.probes]
         assert np.abs(r["wave"][:, :, b] - ref).max() <= TOL * np.abs(ref).max()
 
@@ -160,7 +160,7 @@ def test_dbmixer_full_run_nominal(engines, torch_mod, anchors):
     assert it[0] == a["tran_iters"] and st[0] == 0
     o = _orc().tran(nl.ir_ptr, nl.n_unknowns, nl.nominal_params, 0, nl.tstep, nl.tstop)
     assert wave.shape == (1, 50001, 31)
-    assert rel_err(wave[0], o["rows"][:, 1:], nl.n_node_eq).max() < TOL
+    assert rel_err(wave[0], o["rows"][:, 1:]).max() < TOL
     for eqname, s in a["last_row"].items():
         i = nl.eq_names.index(eqname)
         floor = 1e-6
@@ -186,7 +186,7 @@ def test_dbmixer_full_run_monte_carlo_instances(engines, torch_mod):
     for b in (1, 37, 63):
         o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstop, want_rows=False)
         assert o["n_steps"] == 50000 and its[b] == o["iters"], (b, its[b], o["iters"])
-        assert rel_err(xs[:, b], o["x_final"], nl.n_node_eq).max() < TOL
+        assert rel_err(xs[:, b], o["x_final"]).max() < TOL
 
 
 # --------------------------------------- scheduled (lane-per-instance) kernels
@@ -212,7 +212,7 @@ def test_scheduled_equals_general_on_mc_batch(engines, torch_mod):
     assert np.array_equal(fast["iters"], slow["iters"])
     assert not (fast["status"] & FALLBACK).any()
     assert np.array_equal(fast["status"], slow["status"])
-    assert rel_err(fast["x"].T, slow["x"].T, nl.n_node_eq).max() < TOL
+    assert rel_err(fast["x"].T, slow["x"].T).max() < TOL
 
 
 def test_switching_circuit_alternatives_and_hybrid_stepping(engines, torch_mod):
@@ -231,7 +231,7 @@ def test_switching_circuit_alternatives_and_hybrid_stepping(engines, torch_mod):
     assert np.array_equal(fast["step_iters"], slow["step_iters"])
     assert np.array_equal(fast["iters"], slow["iters"])
     assert np.array_equal(fast["status"] & NOFB, slow["status"])
-    assert rel_err(fast["x"].T, slow["x"].T, nl.n_node_eq).max() < TOL
+    assert rel_err(fast["x"].T, slow["x"].T).max() < TOL
     n_fb = int(((fast["status"] & FALLBACK) != 0).sum())
     assert n_fb < B // 4                      # the recorded alternatives cover almost every instance
     ph = params.cpu().numpy()
@@ -239,13 +239,13 @@ def test_switching_circuit_alternatives_and_hybrid_stepping(engines, torch_mod):
     for b in [0, 3, B - 1] + list(flagged[:2]):
         o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, int(b), nl.tstep, nl.tstop, want_rows=False, want_step_iters=True)
         assert fast["iters"][b] == o["iters"] and np.array_equal(fast["step_iters"][:, b], o["step_iters"])
-        assert rel_err(fast["x"][:, b], o["x_final"], nl.n_node_eq).max() < TOL
+        assert rel_err(fast["x"][:, b], o["x_final"]).max() < TOL
     # at 3e-11 s the first alternative holds for every factorisation: no hand-over at all
     r = _run_tran(torch_mod, eng, params[:, :8].contiguous(), 2000, 3e-11)
     assert not (r["status"] & FALLBACK).any()
     o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, 1, 3e-11, 3e-11 * 2000, want_rows=False)
     assert r["iters"][1] == o["iters"]
-    assert rel_err(r["x"][:, 1], o["x_final"], nl.n_node_eq).max() < TOL
+    assert rel_err(r["x"][:, 1], o["x_final"]).max() < TOL
 
 
 def test_hybrid_stepping_when_no_alternative_fits(torch_mod, tmp_path, monkeypatch):
@@ -266,13 +266,13 @@ def test_hybrid_stepping_when_no_alternative_fits(torch_mod, tmp_path, monkeypat
     eng.jit_scheduled(params, plan_steps=3)                          # 3 quiet steps: one sequence only
     assert eng.tran_kernel == "scheduled"
     for rounds in ("4", "1", "0"):          # 0 rounds: straight from the first violation to the final launch
-        monkeypatch.setenv("CSIM_HYBRID_ROUNDS", rounds)
+        eng.set_option("hybrid_rounds", rounds)
         fast = _run_tran(torch_mod, eng, params, 300, nl.tstep, want_step_iters=True)
         assert ((fast["status"] & FALLBACK) != 0).any(), rounds      # the hand-over really happened
         assert np.array_equal(fast["step_iters"], slow["step_iters"]), rounds
         assert np.array_equal(fast["iters"], slow["iters"]), rounds
         assert np.array_equal(fast["status"] & NOFB, slow["status"]), rounds
-        assert rel_err(fast["x"].T, slow["x"].T, nl.n_node_eq).max() < TOL, rounds
+        assert rel_err(fast["x"].T, slow["x"].T).max() < TOL, rounds
 
 
 def test_scheduled_kernel_ragged_batch(engines, torch_mod):
@@ -318,7 +318,7 @@ def test_batch4096_invariances(engines, torch_mod):
     for j, b in enumerate((0, 1, 4095)):
         o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, j, nl.tstep, nl.tstep * steps, want_rows=False)
         assert whole["iters"][b] == o["iters"]
-        assert rel_err(whole["x"][:, b], o["x_final"], nl.n_node_eq).max() < TOL
+        assert rel_err(whole["x"][:, b], o["x_final"]).max() < TOL
 
 
 # ------------------------------------------------ host-pointer API, edge cases
@@ -341,7 +341,7 @@ def test_host_api_instance_major_params(engines):
     for b in range(5):
         xo, ito, sto = _orc().dc(nl.ir_ptr, nl.n_unknowns, tab, b)
         assert it[b] == ito and st[b] == sto
-        assert rel_err(x[b], xo, nl.n_node_eq).max() < TOL
+        assert rel_err(x[b], xo).max() < TOL
 
 
 def test_error_codes(engines):
@@ -374,11 +374,11 @@ def test_linear_circuit_direct_dc_and_rc_transient(torch_mod):
     x, it, st = eng.dc_host(B=2)
     xo, ito, sto = _orc().dc(nl.ir_ptr, nl.n_unknowns, nl.nominal_params)
     assert it[0] == ito == 1 and st[0] == sto
-    assert rel_err(x[0], xo, nl.n_node_eq).max() < TOL
+    assert rel_err(x[0], xo).max() < TOL
     wave, xf, itr, stt = eng.tran_host(B=2, probes=list(range(nl.n_unknowns)))
     o = _orc().tran(nl.ir_ptr, nl.n_unknowns, nl.nominal_params, 0, nl.tstep, nl.tstop)
     assert itr[0] == o["iters"] and (stt[0] & NOFB) == o["status"]
-    assert rel_err(wave[0], o["rows"][:, 1:], nl.n_node_eq).max() < TOL
+    assert rel_err(wave[0], o["rows"][:, 1:]).max() < TOL
 
 
 def test_floating_node_gives_zero_vector_and_flag(torch_mod):
@@ -584,16 +584,66 @@ def test_jit_scheduled_kernel_for_a_new_netlist(torch_mod, tmp_path, monkeypatch
     fast = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
     assert np.array_equal(fast["step_iters"], slow["step_iters"])
     assert np.array_equal(fast["status"] & NOFB, slow["status"])
-    assert rel_err(fast["x"].T, slow["x"].T, nl.n_node_eq).max() < TOL
+    assert rel_err(fast["x"].T, slow["x"].T).max() < TOL
     assert ((fast["status"] & FALLBACK) != 0).sum() < B // 2      # the fast path really ran for most
     ph = params.cpu().numpy()
     o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, 5, nl.tstep, nl.tstep * steps, want_rows=False)
     assert fast["iters"][5] == o["iters"]
-    assert rel_err(fast["x"][:, 5], o["x_final"], nl.n_node_eq).max() < TOL
+    assert rel_err(fast["x"][:, 5], o["x_final"]).max() < TOL
     # second engine: the cached library is reused (no compile)
     eng2 = Engine(nl, 0)
     eng2.jit_scheduled(params, plan_steps=300)
     assert eng2.tran_kernel == "scheduled"
+
+
+def test_non_convergent_instances_leave_the_fast_path(torch_mod, tmp_path, monkeypatch):
+    """tanalisis.cpp:369-376: a step whose Newton iteration ends at the cap (50) is kept with a WARNING.
+    Such instances are chaotic -- the generated kernel's FMA contraction moves them by +-1-2 iterations
+    per step -- so the generated kernel treats 'cap reached' like a failed pivot check and the
+    bit-faithful general kernel redoes the step.  Here the kernel is generated FROM the pivot sequences
+    of a non-convergent instance, so nothing but that rule keeps those instances off the fast path.
+    Bar: per-step NR counts and status equal to the general kernel on all 96 instances, state within
+    1e-9; the non-convergent ones also against the oracle."""
+    from circuitsimulator_amd import Engine, Netlist
+    monkeypatch.setenv("CSIM_JIT_DIR", str(tmp_path / "jit"))
+    nl = Netlist.from_text(INVERTER_CHAIN)
+    eng = Engine(nl, 0)
+    B, steps = 96, 600
+    params = eng.mc_params(4242, 0.05, 0, B)
+    slow = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+    nonconv = np.where((slow["status"] & 0x02) != 0)[0]
+    assert len(nonconv) >= 3, "the seed no longer yields non-convergent samples: pick another"
+    assert (slow["step_iters"][:, nonconv].max(axis=0) == 50).all()
+    seqs, other = eng.record_pivot_schedules(params, int(nonconv[0]), nl.tstep, steps)
+    assert other == 0
+    eng.jit_with_schedules([s for s, _ in seqs[:4]])
+    assert eng.tran_kernel == "scheduled"
+    fast = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True, chunks=[250, 350])
+    assert np.array_equal(fast["step_iters"], slow["step_iters"])
+    assert np.array_equal(fast["status"] & NOFB, slow["status"])
+    assert rel_err(fast["x"].T, slow["x"].T).max() < TOL
+    assert ((fast["status"][nonconv] & FALLBACK) != 0).all()          # every one of them was handed over
+    conv = np.setdiff1d(np.arange(B), nonconv)
+    assert ((fast["status"][conv] & FALLBACK) == 0).sum() > len(conv) // 2      # and the fast path still ran
+    ph = params.cpu().numpy()
+    for b in list(nonconv[:3]) + [0]:
+        o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, int(b), nl.tstep, nl.tstep * steps, want_rows=False,
+                        want_step_iters=True)
+        assert np.array_equal(fast["step_iters"][:, b], o["step_iters"]), b
+        assert (fast["status"][b] & 0x03) == (o["status"] & 0x03), b        # non-finite / non-convergence bits
+        assert rel_err(fast["x"][:, b], o["x_final"]).max() < TOL, b
+
+
+def test_run_shorter_than_one_step_yields_the_t0_row(engines):
+    """tstop < tstep is legal upstream (nSteps = 0, tanalisis.cpp:238): only the t = 0 row, which is
+    the DC operating point -- also when a scheduled kernel is loaded."""
+    nl, eng = engines["dbmixer"]
+    assert eng.tran_kernel == "scheduled"
+    probes = [1, 2]
+    wave, xf, it, st = eng.tran_host(B=3, tstep=nl.tstep, tstop=0.4 * nl.tstep, tstart=0.0, probes=probes)
+    x_dc, _, _ = eng.dc_host(B=3)
+    assert wave.shape == (3, 1, 2) and (it == 0).all()
+    assert np.array_equal(wave[:, 0, :], x_dc[:, probes]) and np.array_equal(xf, x_dc)
 
 
 # ------------------------------- BASELINE configs[3]: RC ladder, N = 257 unknowns
@@ -685,11 +735,11 @@ def test_mid_size_nonlinear_circuit_big_kernels(torch_mod):
     for b in range(B):
         xo, ito, sto = _orc().dc(nl.ir_ptr, nl.n_unknowns, ph, b)
         assert r["dc_iters"][b] == ito
-        assert rel_err(r["x_dc"][:, b], xo, nl.n_node_eq).max() < TOL
+        assert rel_err(r["x_dc"][:, b], xo).max() < TOL
         o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstep * 40, want_rows=False, want_step_iters=True)
         assert r["iters"][b] == o["iters"] and np.array_equal(r["step_iters"][:, b], o["step_iters"])
         assert (r["status"][b] & NOFB) == o["status"]
-        assert rel_err(r["x"][:, b], o["x_final"], nl.n_node_eq).max() < TOL
+        assert rel_err(r["x"][:, b], o["x_final"]).max() < TOL
 
 
 def test_dc_sweep_axis(torch_mod):
@@ -707,7 +757,7 @@ def test_dc_sweep_axis(torch_mod):
     for j in range(25):
         xo, ito, sto = _orc().dc(nl.ir_ptr, nl.n_unknowns, table, j)
         assert it[j] == ito and st[j] == sto, j
-        assert rel_err(x[:, j], xo, nl.n_node_eq).max() < TOL, j
+        assert rel_err(x[:, j], xo).max() < TOL, j
     # the input node follows dc + v0 (SIN offset 1.5 V): V(101) = value + 1.5
     assert np.allclose(x[nl.eq_names.index("101")], values + 1.5, rtol=0, atol=1e-8)
     out = x[nl.eq_names.index("118")]
@@ -735,7 +785,7 @@ def test_cpp_batch_api(engines):
         o = _orc().tran(nl.ir_ptr, nl.n_unknowns, tab, b, nl.tstep, nl.tstep * steps, want_rows=False)
         assert r["tran_iters"] == o["iters"] and (r["status"] & NOFB) == (o["status"] | sto)
         assert r["rows"] == 2                                   # out_stride = n_steps: t = 0 and the last row
-        assert rel_err(np.array(r["x_final"]), o["x_final"], nl.n_node_eq).max() < TOL
+        assert rel_err(np.array(r["x_final"]), o["x_final"]).max() < TOL
         assert abs(r["wave_last"] - o["x_final"][-1]) <= TOL * max(abs(o["x_final"][-1]), 1e-6)
 
 
@@ -763,11 +813,11 @@ def test_degenerate_element_values_follow_the_reference(variant, torch_mod, tmp_
     for b in (0, B - 1):
         xo, ito, sto = _orc().dc(nl.ir_ptr, nl.n_unknowns, ph, b)
         assert gen["dc_iters"][b] == ito
-        assert rel_err(gen["x_dc"][:, b], xo, nl.n_node_eq).max() < TOL
+        assert rel_err(gen["x_dc"][:, b], xo).max() < TOL
         o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstep * steps, x0=xo, want_rows=False, want_step_iters=True)
         assert gen["iters"][b] == o["iters"] and np.array_equal(gen["step_iters"][:, b], o["step_iters"])
         assert gen["status"][b] == (o["status"] | sto)
-        assert rel_err(gen["x"][:, b], o["x_final"], nl.n_node_eq).max() < TOL
+        assert rel_err(gen["x"][:, b], o["x_final"]).max() < TOL
     if variant == "l_zero":
         assert (gen["status"] & 0x4).all()                       # CSIM_ST_LU_TINY_PIVOT on every instance
     if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
@@ -779,7 +829,7 @@ def test_degenerate_element_values_follow_the_reference(variant, torch_mod, tmp_
         fast = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
         assert np.array_equal(fast["step_iters"], gen["step_iters"])
         assert np.array_equal(fast["status"] & NOFB, gen["status"])
-        assert rel_err(fast["x"].T, gen["x"].T, nl.n_node_eq).max() < TOL
+        assert rel_err(fast["x"].T, gen["x"].T).max() < TOL
 
 
 def test_batch4096_every_instance_against_the_oracle(engines, torch_mod):
@@ -795,7 +845,7 @@ def test_batch4096_every_instance_against_the_oracle(engines, torch_mod):
     for b in range(B):
         o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstep * steps, want_rows=False)
         assert r["iters"][b] == o["iters"], b
-        worst = max(worst, rel_err(r["x"][:, b], o["x_final"], nl.n_node_eq).max())
+        worst = max(worst, rel_err(r["x"][:, b], o["x_final"]).max())
     assert worst < TOL, worst
 
 
@@ -821,21 +871,21 @@ def test_pulse_pwl_sources_general_and_scheduled(torch_mod, tmp_path, monkeypatc
         assert np.array_equal(slow["step_iters"][:, b], o["step_iters"])
         assert slow["status"][b] == o["status"] == 0
         want = o["rows"][:, [1 + q for q in probes]]
-        assert rel_err(slow["wave"][:, :, b], want, nl.n_node_eq).max() < TOL
-        assert rel_err(slow["x"][:, b], o["x_final"], nl.n_node_eq).max() < TOL
+        assert rel_err(slow["wave"][:, :, b], want).max() < TOL
+        assert rel_err(slow["x"][:, b], o["x_final"]).max() < TOL
     eng.jit_scheduled(params, plan_steps=steps)
     assert eng.tran_kernel == "scheduled"
     fast = _run_tran(torch_mod, eng, params, steps, nl.tstep, probes=probes, want_step_iters=True)
     assert np.array_equal(fast["step_iters"], slow["step_iters"])
     assert np.array_equal(fast["status"] & NOFB, slow["status"])
     assert rel_err(fast["wave"].transpose(2, 0, 1).reshape(-1, len(probes)),
-                   slow["wave"].transpose(2, 0, 1).reshape(-1, len(probes)), nl.n_node_eq).max() < TOL
+                   slow["wave"].transpose(2, 0, 1).reshape(-1, len(probes))).max() < TOL
     assert ((fast["status"] & FALLBACK) != 0).sum() < B // 2
     # host API, nominal instance: every CSV column
     wave, xf, it, st = eng.tran_host(B=1, probes=list(range(nl.n_unknowns)))
     o = orc.tran(nl.ir_ptr, nl.n_unknowns, nl.nominal_params, 0, nl.tstep, nl.tstop)
     assert it[0] == o["iters"] and st[0] & NOFB == 0
-    assert rel_err(wave[0], o["rows"][:, 1:], nl.n_node_eq).max() < TOL
+    assert rel_err(wave[0], o["rows"][:, 1:]).max() < TOL
 
 
 # --------------------------------------------- scheduled DC operating-point kernel
@@ -868,13 +918,13 @@ def test_scheduled_dc_kernel_equals_general_and_oracle(engines, torch_mod):
     assert np.array_equal(it_g.cpu().numpy(), it_s.cpu().numpy())
     assert np.array_equal(stg, sts & NOFB)
     assert ((sts & FALLBACK_DC) != 0).sum() <= B // 100       # the scheduled kernel really produced the results
-    assert rel_err(xs.T, xg.T, nl.n_node_eq).max() < TOL
+    assert rel_err(xs.T, xg.T).max() < TOL
     assert t_sched < t_general                                   # and it is the faster path
     ph = params.cpu().numpy()
     for b in (0, 1, 777, 4095):
         xo, ito, sto = _orc().dc(nl.ir_ptr, nl.n_unknowns, ph, b)
         assert it_s[b].item() == ito and (sts[b] & NOFB) == sto
-        assert rel_err(xs[:, b], xo, nl.n_node_eq).max() < TOL
+        assert rel_err(xs[:, b], xo).max() < TOL
 
 
 def test_scheduled_dc_violators_are_replayed_by_the_general_kernel(torch_mod, tmp_path, monkeypatch):
@@ -900,7 +950,7 @@ def test_scheduled_dc_violators_are_replayed_by_the_general_kernel(torch_mod, tm
     assert 0 < nfb <= B
     assert np.array_equal(it_g.cpu().numpy(), it_s.cpu().numpy())
     assert np.array_equal(st_g.cpu().numpy().astype(np.uint32), sts & NOFB)
-    assert rel_err(x_s.cpu().numpy().T, x_g.cpu().numpy().T, nl.n_node_eq).max() < TOL
+    assert rel_err(x_s.cpu().numpy().T, x_g.cpu().numpy().T).max() < TOL
 
 
 # --------------------------------------------------- randomized netlists (general kernels)
@@ -962,7 +1012,7 @@ def test_random_netlists_general_kernels_vs_oracle(torch_mod):
         for b in range(B):
             xo, ito, sto = orc.dc(nl.ir_ptr, nl.n_unknowns, ph, b)
             assert r["dc_iters"][b] == ito, (seed, b, "dc iters", r["dc_iters"][b], ito)
-            assert rel_err(r["x_dc"][:, b], xo, nl.n_node_eq).max() < TOL, (seed, b, "dc x")
+            assert rel_err(r["x_dc"][:, b], xo).max() < TOL, (seed, b, "dc x")
             o = orc.tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstep * steps, want_step_iters=True)
             dc_bits = sto & 0x1C                                    # DC flags live in the same status word
             assert (r["status"][b] & NOFB) == (o["status"] | dc_bits), (seed, b, hex(r["status"][b]), hex(o["status"]), hex(sto))
@@ -970,7 +1020,7 @@ def test_random_netlists_general_kernels_vs_oracle(torch_mod):
             if o["status"] & 0x1:                                   # the reference would have thrown: stopped early
                 continue
             assert np.array_equal(r["step_iters"][:, b], o["step_iters"]), (seed, b, "tran iters")
-            e = rel_err(r["x"][:, b], o["x_final"], nl.n_node_eq).max()
+            e = rel_err(r["x"][:, b], o["x_final"]).max()
             worst = max(worst, e)
             assert e < TOL, (seed, b, e)
     print("random netlists: worst relative deviation %.2e, %d flagged instance runs" % (worst, n_flagged))
@@ -997,10 +1047,10 @@ def test_random_netlists_generated_kernels(torch_mod, tmp_path, monkeypatch):
         assert eng.tran_kernel == "scheduled", seed
         fast = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
         assert np.array_equal(fast["dc_iters"], slow["dc_iters"]), seed
-        assert rel_err(fast["x_dc"].T, slow["x_dc"].T, nl.n_node_eq).max() < TOL, seed
+        assert rel_err(fast["x_dc"].T, slow["x_dc"].T).max() < TOL, seed
         assert np.array_equal(fast["step_iters"], slow["step_iters"]), seed
         assert np.array_equal(fast["status"] & NOFB, slow["status"]), seed
-        assert rel_err(fast["x"].T, slow["x"].T, nl.n_node_eq).max() < TOL, seed
+        assert rel_err(fast["x"].T, slow["x"].T).max() < TOL, seed
         n_dc_kernels += int(((fast["status"] & FALLBACK_DC) != 0).any())
     print("random netlists: %d of 6 circuits had DC instances replayed by the general kernel" % n_dc_kernels)
 
