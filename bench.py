@@ -32,6 +32,9 @@ sys.path.insert(0, HERE)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6 # MI355X FP64 vector peak (256 CUs x 4 SIMDs x 16 FMA lanes x 2 flop x 2.4 GHz)
+N_SIMDS = 1024                 # 256 CUs x 4 SIMDs
+PEAK_CLOCK_HZ = 2.4e9
+VALU_ISSUE_CYCLES = 4          # one wave64 VALU instruction (FP64 FMA: 16 lanes/clk/SIMD) holds a SIMD's issue for 4 cycles
 
 
 def dense_flops(n):
@@ -44,20 +47,51 @@ def algorithmic_bytes_per_iter(N):
     return 8 * (N * N + 3 * N)
 
 
-def hbm_traffic_per_launch(nl, kernel, B, S):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json,
-    written by tools/summarize_profile.py; FETCH_SIZE/WRITE_SIZE collected in separate passes and
-    corrected as MI355X_MICROARCH.md prescribes).  None when this exact workload was not profiled."""
-    path = os.path.join(HERE, "profiles", "hbm_traffic.json")
+def profiled_counters(nl, kernel, B):
+    """Counters of this kernel at this batch size from the committed rocprofv3 PMC passes
+    (profiles/kernel_counters.json, written by tools/summarize_profile.py; FETCH_SIZE / WRITE_SIZE /
+    SQ_INSTS_VALU collected in separate --pmc passes, per NR iteration x instance so that they carry
+    over to any launch length).  None when this exact (circuit, kernel, batch) was not profiled."""
+    path = os.path.join(HERE, "profiles", "kernel_counters.json")
     if not os.path.exists(path):
         return None
     try:
         table = json.load(open(path))
     except Exception:
         return None
-    key = "N%d|%s|B%d|S%d" % (nl.n_unknowns, kernel, B, S)
-    ent = table.get(key)
-    return ent["bytes_per_launch"] if ent else None
+    return table.get("N%d|%s|B%d" % (nl.n_unknowns, kernel, B))
+
+
+def executed_flops_per_unit(eng, nl):
+    """FP64 operations one NR iteration of one instance EXECUTES in the generated kernel: the solve's
+    counts from the generator (csim_engine_sched_info; an FMA = 2, a Newton-refined reciprocal = 1 + 4 FMA)
+    plus the damped update and norm (5 per unknown) -- device evaluation and assembly (a few hundred more)
+    are not counted, so this is a lower bound."""
+    info = eng.sched_info
+    if not info or not info["ops"]:
+        return None
+    o = info["ops"]
+    return 2 * o.get("fma", 0) + o.get("mul", 0) + o.get("addsub", 0) + 9 * o.get("recip", 0) + 5 * nl.n_unknowns
+
+
+def valu_roof(units_per_s, counters, B, lanes_per_instance, flops_exec):
+    """The roof that binds these kernels: FP64 VALU issue.  achieved_frac = wave-level VALU instructions
+    the kernel issues per second x 4 cycles each / (1024 SIMDs x 2.4 GHz); waves = what the batch can keep
+    resident (the lane-per-instance kernel needs 64 instances per wave, one wave per SIMD)."""
+    waves = -(-B * lanes_per_instance // 64)
+    rec = {"bound": "fp64 VALU issue (%d cycles per wave instruction, %d SIMDs, %.1f GHz)"
+                    % (VALU_ISSUE_CYCLES, N_SIMDS, PEAK_CLOCK_HZ / 1e9),
+           "lanes_per_instance": lanes_per_instance,
+           "waves": waves, "simd_occupancy": min(1.0, waves / N_SIMDS),
+           "executed_flops_per_unit": flops_exec,
+           "executed_tflops": units_per_s * flops_exec / 1e12 if flops_exec else None,
+           "valu_wave_insts_per_unit": None, "achieved_frac": None, "source": None}
+    if counters and counters.get("valu_wave_insts_per_unit"):
+        ipu = counters["valu_wave_insts_per_unit"]
+        rec["valu_wave_insts_per_unit"] = ipu
+        rec["achieved_frac"] = units_per_s * ipu * VALU_ISSUE_CYCLES / (N_SIMDS * PEAK_CLOCK_HZ)
+        rec["source"] = counters.get("source")
+    return rec
 
 
 def cpu_baseline(nl, params_host, n_inst, tstep, n_tsteps, threads=1):
@@ -85,7 +119,13 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
-    ap.add_argument("--tsteps", type=int, default=200, help="time steps per bench step (launch)")
+    ap.add_argument("--tsteps", type=int, default=2000,
+                    help="time steps per bench step (one csim_tran_batch_dev call); 2000 x (5 + 20) steps = the "
+                         "netlist's whole 50 000-step run")
+    ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 16],
+                    help="scheduled kernel: lanes per instance (0 = the engine picks by batch size)")
+    ap.add_argument("--dump-gathered", default="",
+                    help="rank 0 writes the gathered probe voltages and per-rank NR totals to this .npz (tests)")
     ap.add_argument("--netlist", default=os.path.join(HERE, "tests", "golden", "dbmixer.sp"))
     ap.add_argument("--ladder", type=int, default=0,
                     help="use the synthetic RC ladder with this many nodes instead of --netlist (configs[3]: 256)")
@@ -134,6 +174,8 @@ def main():
     eng = Engine(nl, local_rank)
     if args.kernel != "auto":
         eng.set_kernel(args.kernel)
+    if args.lanes:
+        eng.set_option("lanes_per_instance", args.lanes)
     N, B, S = nl.n_unknowns, args.batch, args.tsteps
     tstep = nl.tstep
 
@@ -211,12 +253,21 @@ def main():
                  "flagged_instances": int((stl & 0xA7).ne(0).sum().item())}
         del pl, xl, itl, stl
 
+    if args.dump_gathered and rank == 0:
+        np.savez(args.dump_gathered, gathered=all_v.cpu().numpy(), total_iters=total_iters)
+
     if rank == 0:
         value = total_iters / wall_max
         avg_kern_s = float(np.mean(kern_ms)) * 1e-3
         iters_per_launch = local_iters / args.steps
         abytes = algorithmic_bytes_per_iter(N)
         achieved = iters_per_launch * abytes / avg_kern_s / 1e9
+        kernel = eng.tran_kernel
+        lanes = eng.lanes_for_batch(B) if kernel == "scheduled" else 64
+        ckey = kernel if lanes in (1, 64) else "%s%d" % (kernel, lanes)
+        counters = profiled_counters(nl, ckey, B)
+        flops_exec = executed_flops_per_unit(eng, nl) if kernel == "scheduled" else None
+        frac = achieved / HBM_PEAK_GBS
         rec = {
             "metric": "NR-iteration x instances / sec (transient)",
             "value": value,
@@ -237,20 +288,30 @@ def main():
                                N, B, args.sigma, args.seed, S, tstep),
                 "batch_per_gpu": B,
                 "time_steps_per_step": S,
-                "kernel": eng.tran_kernel,
+                "kernel": kernel,
+                "lanes_per_instance": lanes,
                 "nr_iters_per_step": iters_per_launch,
                 "flagged_instances": n_bad,
             },
+            # SURVEY.md 8(d) accounting: the bytes of the DENSE system the reference materialises per NR
+            # iteration, 8(N^2+3N), not bytes this kernel moves (it keeps the sparse system on chip; what it
+            # really moves is `traffic`).  A fraction above 1 is therefore possible and says only that the
+            # dense work was not done; the roof that binds is `roofline_valu`.
             "roofline": {
                 "bound": "hbm",
+                "accounting": "dense_equivalent_bytes (SURVEY.md 8d: 8*(N^2+3N) per NR iteration x instance)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": hbm_traffic_per_launch(nl, eng.tran_kernel, B, S),
+                "frac": frac,
+                "artefact": frac > 1.0,
+                "traffic": (counters["hbm_bytes_per_unit"] * iters_per_launch) if counters and counters.get("hbm_bytes_per_unit") else None,
+                "traffic_source": counters.get("source") if counters else None,
                 "algorithmic_bytes_per_unit": abytes,
                 "kernel_avg_ms": avg_kern_s * 1e3,
             },
+            "roofline_valu": valu_roof(iters_per_launch / avg_kern_s, counters, B, 1 if lanes == 64 else lanes, flops_exec)
+                             if kernel == "scheduled" else None,
             # the dense LU + substitution flops the reference spends per NR iteration,
             # n(n-1)/2 + (n-1)n(2n-1)/3 + 2n(n-1) + n, against the FP64 vector peak (the kernels execute far fewer:
             # structural zeros are never touched)
@@ -264,13 +325,21 @@ def main():
             "gathered_shape": list(all_v.shape),
         }
         if large is not None:
-            large["roofline_frac"] = large["value"] * abytes / 1e9 / HBM_PEAK_GBS
+            lf = large["value"] * abytes / 1e9 / HBM_PEAK_GBS
+            large["roofline_frac"] = lf
+            large["roofline_artefact"] = lf > 1.0
+            ll = eng.lanes_for_batch(large["batch_per_gpu"]) if kernel == "scheduled" else 64
+            lkey = kernel if ll in (1, 64) else "%s%d" % (kernel, ll)
+            large["lanes_per_instance"] = ll
+            if kernel == "scheduled":
+                large["roofline_valu"] = valu_roof(large["value"] / world, profiled_counters(nl, lkey, large["batch_per_gpu"]),
+                                                   large["batch_per_gpu"], ll, flops_exec)
             rec["large_batch"] = large
         if world == 1 and not args.no_cpu:
             # CPU baseline: the oracle (port of the reference algorithm), 1 thread,
             # on the first instances of the same parameter table
             ph = params[:, :256].cpu().numpy()
-            s_cpu = min(S * args.steps, 2000)
+            s_cpu = min(S * args.steps, 2000)                  # bounded sample: at most 2000 time steps per instance
             est_per_inst = 10.0 * s_cpu
             n_cpu = int(max(1, min(ph.shape[1], round(args.cpu_iters / est_per_inst))))
             ci, cdt = cpu_baseline(nl, ph, n_cpu, tstep, s_cpu)

@@ -58,6 +58,8 @@ PROTOTYPES = {
     "csim_engine_destroy": (None, [_vp]),
     "csim_engine_tran_kernel": (_cp, [_vp]),
     "csim_engine_set_kernel": (C.c_int, [_vp, _i32]),
+    "csim_engine_sched_info": (_cp, [_vp]),
+    "csim_engine_lanes_for_batch": (C.c_int, [_vp, _i32]),
     "csim_mc_params_dev": (C.c_int, [_vp, _u64, _dbl, _i64, _i32, _vp, _vp]),
     "csim_mc_params_host": (C.c_int, [_vp, _u64, _dbl, _i64, _i32, _vp]),
     "csim_dc_batch_dev": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),

@@ -840,6 +840,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
     };
 
     // ---- the alternatives are tried in order; lanes whose checks failed take the next one
+    CodegenStats firstAlt;
     g.out << g.ind << "bool pv = false;     // every schedule tried so far failed its pivot checks\n";
     for (int i = 0; i < N; ++i) g.out << g.ind << "double xr" << i << ";\n";
     const std::vector<PivotSchedule>& alternatives = opt.dcMode ? set.dcAlts : set.alts;
@@ -849,6 +850,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         else g.out << g.ind << "if (__any(active && pv)) {   // alternative schedule " << alt << "\n";
         g.out << g.ind << "bool " << pvName << " = false;\n";
         const std::vector<AV> sol = emitSolve(alternatives[alt], pvName);
+        if (alt == 0) firstAlt = g.st;             // operation counts of ONE solve on the most frequent schedule
         for (int i = 0; i < N; ++i) {
             if (alt == 0) g.out << g.ind << "xr" << i << " = " << g.ref(sol[static_cast<std::size_t>(i)]) << ";\n";
             else g.out << g.ind << "xr" << i << " = pv ? " << g.ref(sol[static_cast<std::size_t>(i)]) << " : xr" << i << ";\n";
@@ -962,7 +964,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
 
     }
 
-    if (statsOut) *statsOut = g.st;
+    if (statsOut) *statsOut = firstAlt;
     return ldsNext;
 }
 
@@ -1010,7 +1012,9 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     };
     // lean: 40 KB of LDS per wave (4 waves per CU): x, then finished U rows up to the budget;
     // for N > 80 the iterate alone exceeds that and the kernel runs fewer waves per CU
-    const int ldsLean = emitVariant({"csim_tran_sched_kernel", false, false, leanBudget > 0 ? leanBudget : 0}, statsOut);
+    CodegenStats leanStats;
+    const int ldsLean = emitVariant({"csim_tran_sched_kernel", false, false, leanBudget > 0 ? leanBudget : 0}, &leanStats);
+    if (statsOut) *statsOut = leanStats;
     if (ldsLean < 0) return std::string();          // the iterate does not fit LDS: no scheduled kernel
     // rich: same residency, every finished U row parked (more LDS per wave: fewer waves per CU)
     const int ldsRich = emitVariant({"csim_tran_sched_kernel_rich", false, false, -1}, nullptr);
@@ -1049,7 +1053,9 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     src << "extern \"C\" unsigned long long csim_sched_hash(void) { return " << hbuf << "; }\n"
         << "extern \"C\" unsigned long long csim_sched_topology(void) { return " << tbuf << "; }\n"
         << "extern \"C\" const char* csim_sched_info(void) { return \"" << label << " N=" << N << " schedule="
-        << set.str() << " lds_doubles_per_lane=" << ldsLean << "/" << ldsRich << "\"; }\n"
+        << set.str() << " lds_doubles_per_lane=" << ldsLean << "/" << ldsRich
+        << " ops_per_solve: fma=" << leanStats.nFma << " mul=" << leanStats.nMul << " addsub=" << leanStats.nAddSub
+        << " recip=" << leanStats.nRecip << " cmp=" << leanStats.nCmp << "\"; }\n"
         << "// the recorded alternatives, [n_alts][N] pivot row positions (the engine hands them to the\n"
         << "// general kernel so that it can tell when an instance is back on a known sequence)\n"
         << "extern \"C\" const int* csim_sched_alts(int* nAlts, int* n)\n{\n    static const int table[] = {";

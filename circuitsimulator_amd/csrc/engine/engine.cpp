@@ -278,6 +278,11 @@ const char* csim_engine_tran_kernel(const csim_engine* eng)
     return (eng->schedLaunch && eng->kernelChoice != 1) ? "scheduled" : "general";
 }
 
+const char* csim_engine_sched_info(const csim_engine* eng)
+{
+    return (eng && eng->schedLaunch) ? eng->schedInfo.c_str() : "";
+}
+
 int csim_engine_set_kernel(csim_engine* eng, int32_t which)
 {
     if (!eng || which < 0 || which > 2) return CSIM_ERR_ARG;
@@ -343,6 +348,12 @@ static int schedVariantFor(const csim_engine* eng, int32_t B)
     // auto: sixteen lanes per instance while the batch cannot give every SIMD a wave of its own
     // (lane-per-instance needs 64 instances per wave and the chip has 1024 SIMDs)
     return (eng->schedGroupLanes == 16 && (int64_t)B * 16 <= 64 * 1024 * 2) ? 16 : 0;
+}
+
+extern "C" int csim_engine_lanes_for_batch(const csim_engine* eng, int32_t B)
+{
+    if (!eng || !eng->schedLaunch || eng->kernelChoice == 1) return 0;
+    return schedVariantFor(eng, B) == 16 ? 16 : 1;
 }
 
 // per-instance fallback mask and progress counters of the scheduled kernels

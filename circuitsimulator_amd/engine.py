@@ -137,6 +137,25 @@ class Engine:
     def tran_kernel(self):
         return capi.lib().csim_engine_tran_kernel(self._h).decode()
 
+    @property
+    def sched_info(self):
+        """csim_engine_sched_info parsed: dict(text=..., ops=dict(fma, mul, addsub, recip, cmp)) or None"""
+        text = capi.lib().csim_engine_sched_info(self._h).decode()
+        if not text:
+            return None
+        ops = {}
+        if "ops_per_solve:" in text:
+            for item in text.split("ops_per_solve:")[1].split():
+                k, _, v = item.partition("=")
+                if v.isdigit():
+                    ops[k] = int(v)
+        return dict(text=text, ops=ops)
+
+    def lanes_for_batch(self, B):
+        """lanes per instance of the transient kernel for B instances: 1 / 16 (scheduled), 64 (general)"""
+        n = capi.lib().csim_engine_lanes_for_batch(self._h, int(B))
+        return n if n else 64
+
     def set_kernel(self, which):
         capi.check(capi.lib().csim_engine_set_kernel(self._h, {"auto": 0, "general": 1, "scheduled": 2}[which]))
 

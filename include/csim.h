@@ -109,6 +109,13 @@ void csim_engine_destroy(csim_engine* eng);
  * dense LDS LU with dynamic pivoting) or "scheduled" (lane-per-instance,
  * circuit-specialised code with a verified pivot schedule)                   */
 const char* csim_engine_tran_kernel(const csim_engine* eng);
+/* description of the loaded generated library ("" if none): circuit, pivot schedules, LDS doubles
+ * per lane, and the floating-point operations ONE solve on the first schedule executes
+ * ("ops_per_solve: fma=.. mul=.. addsub=.. recip=.. cmp=..")                                   */
+const char* csim_engine_sched_info(const csim_engine* eng);
+/* lanes per instance the scheduled transient kernel would use for a batch of B instances (1 or 16;
+ * 0 = the general kernel runs: one 64-lane wavefront per instance)                              */
+int  csim_engine_lanes_for_batch(const csim_engine* eng, int32_t B);
 /* force a kernel family: 0 = auto, 1 = general only, 2 = scheduled required  */
 int  csim_engine_set_kernel(csim_engine* eng, int32_t which);
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/prof_<tag>/ (written by tools/profile_bench.sh on the GPU box) into the
 committed artefacts profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.csv,
-profiles/<tag>_summary.md and profiles/hbm_traffic.json (read by bench.py for roofline.traffic).
+profiles/<tag>_summary.md and profiles/kernel_counters.json (read by bench.py for roofline.traffic
+and roofline_valu).
 
 FETCH_SIZE / WRITE_SIZE come from separate --pmc passes and are in KiB (x1024).  The gfx950
 correction of MI355X_MICROARCH.md (FETCH_SIZE reads 1/2 for wide 16 B/lane streams) is NOT applied:
@@ -72,11 +73,22 @@ def main():
     fetch = p.get("FETCH_SIZE", 0.0) * 1024
     write = p.get("WRITE_SIZE", 0.0) * 1024
     cfg = bench["config"]
-    key = "N%d|%s|B%d|S%d" % (31 if "N=31" in cfg["workload"] else 13, cfg["kernel"], cfg["batch_per_gpu"],
-                              cfg["time_steps_per_step"])
-    tpath = os.path.join(dst, "hbm_traffic.json")
+    # per NR iteration x instance, so that bench.py can scale to any launch length
+    units = float(cfg["nr_iters_per_step"])
+    lanes = cfg.get("lanes_per_instance", 1)
+    kname = cfg["kernel"] if lanes in (1, 64) else "%s%d" % (cfg["kernel"], lanes)
+    import re
+    n_unknowns = int(re.search(r"N=(\d+)", cfg["workload"]).group(1))
+    key = "N%d|%s|B%d" % (n_unknowns, kname, cfg["batch_per_gpu"])
+    tpath = os.path.join(dst, "kernel_counters.json")
     table = json.load(open(tpath)) if os.path.exists(tpath) else {}
-    table[key] = {"bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
+    m = meta.get(dname, ("",) * 7)
+    table[key] = {"hbm_bytes_per_unit": (fetch + write) / units, "fetch_bytes_per_unit": fetch / units,
+                  "write_bytes_per_unit": write / units,
+                  "valu_wave_insts_per_unit": p.get("SQ_INSTS_VALU", 0.0) / units,
+                  "lds_wave_insts_per_unit": p.get("SQ_INSTS_LDS", 0.0) / units,
+                  "waves_per_launch": p.get("SQ_WAVES", 0.0), "vgpr": m[4], "agpr": m[5], "scratch_bytes": m[3],
+                  "lds_bytes": m[2], "time_steps_per_launch": cfg["time_steps_per_step"],
                   "source": "profiles/%s_pmc.csv (%s)" % (tag, dname)}
     json.dump(table, open(tpath, "w"), indent=1, sort_keys=True)
 
