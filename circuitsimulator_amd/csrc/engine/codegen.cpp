@@ -770,7 +770,10 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
                     if (!mb.empty()) e += " & (" + absP + " > " + mb + ")";
                     g.out << g.ind << pvName << " |= !(" << e << ");\n";
                 } else {
-                    for (const std::string& c : conds) g.out << g.ind << pvName << " |= !" << c << ";\n";
+                    // constant pivot (a +-1 incidence entry) against run-time candidates: short-circuit form.
+                    // Its block boundaries are load-bearing for hipcc's register allocation of this body
+                    // (branch-free "|=" here: 46 -> 243 spilled registers, 8.5e8 -> 4.8e8 at B = 4096).
+                    for (const std::string& c : conds) g.out << g.ind << pvName << " = " << pvName << " || !" << c << ";\n";
                 }
             }
             if (p != k) {
@@ -928,13 +931,14 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
           << g.ind << "    else {\n"
           << g.ind << "        ++it;\n";
         for (int i = 0; i < N; ++i) o << g.ind << "        X(" << i << ") = xn" << i << ";\n";
-        // NR cap reached (tanalisis.cpp:372-376): the reference warns and moves on with the last iterate.
-        // A Newton iteration that does not converge is chaotic -- the 1e-16 of FMA contraction in this
-        // kernel grows to +-1-2 iterations per step and 4e-7 in the state -- so such a step is treated like
-        // a failed pivot check: the lane stops at the step's checkpoint and the bit-faithful general
-        // kernel redoes the step (and sets CSIM_ST_TRAN_NONCONV).
+        // Slow steps leave this kernel (plan.hpp slowStepIters).  The reference keeps a step that reaches
+        // the NR cap with a WARNING (tanalisis.cpp:372-376); steps that need anywhere near that many passes
+        // are chaotic -- the 1e-16 of FMA contraction in this kernel moves them by +-1..4 passes and 4e-7
+        // in the state -- so such a step is treated like a failed pivot check: the lane stops at the step's
+        // checkpoint and the bit-faithful general kernel redoes it (and sets CSIM_ST_TRAN_NONCONV if due).
+        const int slowIters = slowStepIters(K.tran_tol, K.tran_alpha, K.tran_max_iters);
         o << g.ind << "        if (err < " << lit(K.tran_tol) << ") active = false;\n"
-          << g.ind << "        else if (iter == " << (K.tran_max_iters - 1) << ") { viol = true; active = false; }\n"
+          << g.ind << "        else if (iter >= " << (slowIters - 1) << ") { viol = true; active = false; }\n"
           << g.ind << "    }\n"
           << g.ind << "}\n";
 

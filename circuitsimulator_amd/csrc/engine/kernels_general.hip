@@ -176,11 +176,12 @@ k_tran_general(GenPlan pl, const double* __restrict__ params, int B, double dt,
     long long itTotal = 0;
     bool aborted = (st & CSIM_ST_TRAN_NONFINITE) != 0;                 // an instance the reference would have thrown on stays stopped
 
+    const int slowIters = slowStepIters(K.tran_tol, K.tran_alpha, K.tran_max_iters);
     long long sLast = d0;
     for (long long s = d0 + 1; s <= sEnd && !aborted; ++s) {
         sLast = s;
         bool stepKnown = curPiv != nullptr;     // every factorisation of this step on a known sequence?
-        bool stepConverged = false;             // a step that ends at the NR cap is not handed back either
+        bool stepConverged = false;             // a slow step (plan.hpp slowStepIters) is not handed back either
         const long long gstep = stepFirst + s;
         const double tNow = (double)(int)gstep * dt;                    // :256
         terms_step_tran(pl, Pv, T, xp, tNow, lane);
@@ -203,7 +204,7 @@ k_tran_general(GenPlan pl, const double* __restrict__ params, int B, double dt,
             const double err = norm_in_order(xn - xo, sc, N, lane);     // :366
             if (lane < N) xs[lane] = xn;                                // :367
             wave_sync();
-            if (err < K.tran_tol) { stepConverged = true; break; }      // :369-371
+            if (err < K.tran_tol) { stepConverged = it <= slowIters; break; }   // :369-371
             if (iter == K.tran_max_iters - 1) st |= CSIM_ST_TRAN_NONCONV;   // :372-376
         }
         itTotal += it;

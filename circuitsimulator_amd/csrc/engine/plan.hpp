@@ -65,4 +65,24 @@ inline int ldFor(int N) { const int need = N + 1; return (need & 1) ? need : nee
 
 AssemblyPlan buildAssemblyPlan(const csim_ir& ir);
 
+// Slow-step rule of the hybrid stepping.  A damped Newton update x += alpha (x_raw - x) of a well-behaved
+// iteration contracts the error by (1 - alpha) per pass, so an initial error as large as 1e3 (volts) is
+// below tol after ceil(log(tol * 1e-3) / log(1 - alpha)) passes: 35 for the transient (tol 1e-6, alpha
+// 0.45).  A time step that needs more is not contracting at the damping rate; such steps were measured
+// to be chaotic (the 42..50-pass steps of the inverter-chain test circuit move by +-1..4 passes under
+// the 1e-16 of an FMA contraction), so the generated kernels do not keep them: the step is redone by the
+// bit-faithful general kernel, which also does not hand an instance back after such a step.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int slowStepIters(double tol, double alpha, int cap)
+{
+    if (!(alpha > 0.0 && alpha < 1.0) || !(tol > 0.0)) return cap;
+    // computed with integer steps so that host (generator) and device agree exactly
+    int n = 0;
+    double e = 1.0e3;
+    while (e >= tol && n < cap) { e *= (1.0 - alpha); ++n; }
+    return n < cap ? n : cap;
+}
+
 } // namespace csim

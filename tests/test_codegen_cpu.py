@@ -68,3 +68,34 @@ def test_schedule_contradicting_constant_entries_falls_back(codegen, tmp_path):
     p, src = _run(codegen, netlist_path("buffer.sp"), "0:12\n", tmp_path)
     assert p.returncode == 0, p.stderr
     assert "scheduled pivot is a structural zero" in src
+
+
+def test_generated_dbmixer_kernel_register_allocation(codegen, tmp_path):
+    """Tripwire for the headline kernel's speed, checkable without a GPU: hipcc's register allocation of
+    the 3000-instruction lane-per-instance body is fragile (one changed form of the pivot checks once
+    took it from 46 to 243 spilled registers and halved the measured rate).  The shipped kernel must stay
+    within a small scratch frame and must not lose the one-wave-per-SIMD register budget."""
+    import re
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    text = open(os.path.join(SCHED, "dbmixer.sched")).read()
+    p, src = _run(codegen, netlist_path("dbmixer.sp"), text, tmp_path)
+    assert p.returncode == 0, p.stderr
+    asm = tmp_path / "x.s"
+    c = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+                        str(tmp_path / "x.hip"), "-o", str(asm)], capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    meta = {}
+    name = None
+    for line in asm.read_text().splitlines():
+        m = re.match(r"\s+\.name:\s+(\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.match(r"\s+\.(private_segment_fixed_size|vgpr_spill_count|vgpr_count):\s+(\d+)", line)
+        if m and name:
+            meta.setdefault(name, {})[m.group(1)] = int(m.group(2))
+    lean = meta["csim_tran_sched_kernel"]
+    assert lean["private_segment_fixed_size"] <= 320, lean         # bytes of scratch per lane (shipped: 180)
+    assert lean["vgpr_spill_count"] <= 80, lean                    # shipped: 44
+    assert meta["csim_dc_sched_kernel"]["private_segment_fixed_size"] == 0
