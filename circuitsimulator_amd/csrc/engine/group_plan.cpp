@@ -1,0 +1,355 @@
+// group_plan.cpp -- see group_plan.hpp: plan builder and host interpreter.
+#include "group_plan.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+
+namespace csim {
+
+namespace {
+
+struct Kind {
+    enum { ZERO, CONST, DYN } k = ZERO;
+    double c = 0.0;
+    bool zero() const { return k == ZERO; }
+};
+
+// kind of stamp a MOS channel term is, from (term offset, negate): see GroupPlan::mosDest
+int mosStampKind(int termOffset, bool neg)
+{
+    switch (termOffset) {
+        case T_M_GD: return neg ? 4 : 0;
+        case T_M_GG: return neg ? 5 : 1;
+        case T_M_GS: return neg ? 6 : 2;
+        case T_M_CST: return neg ? 3 : 7;
+        default: return -1;
+    }
+}
+
+} // namespace
+
+bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch, GroupPlan& gp)
+{
+    const int N = ir.n_unknowns;
+    gp = GroupPlan();
+    if (N <= 0 || N > 3 * kGroupLanes) return false;         // register budget: 3 slots of N+1 doubles
+    if (static_cast<int>(sch.pivotPos.size()) != N) return false;
+    gp.N = N;
+    gp.S = (N + kGroupLanes - 1) / kGroupLanes;
+    const int S = gp.S, LD = ap.LD;
+    const GatherPlan& g = ap.tran;
+
+    // ---- which terms belong to a MOSFET's channel linearisation (they change every iteration)
+    std::vector<int> mosOfTerm(static_cast<std::size_t>(ap.nTerms), -1), offOfTerm(static_cast<std::size_t>(ap.nTerms), -1);
+    for (int e = 0; e < ir.n_elems; ++e) {
+        if (ir.kind[e] != CSIM_NMOS && ir.kind[e] != CSIM_PMOS) continue;
+        const int m = static_cast<int>(gp.mosElem.size());
+        gp.mosElem.push_back(e);
+        for (int o = T_M_GD; o <= T_M_CST; ++o) {
+            mosOfTerm[static_cast<std::size_t>(ap.termBase[static_cast<std::size_t>(e)] + o)] = m;
+            offOfTerm[static_cast<std::size_t>(ap.termBase[static_cast<std::size_t>(e)] + o)] = o;
+        }
+    }
+    // exact constants: the global ONE and the inductor incidence (precondition L > 0, checked per instance)
+    std::vector<char> termIsOne(static_cast<std::size_t>(ap.nTerms), 0);
+    termIsOne[static_cast<std::size_t>(ap.termOne)] = 1;
+    for (int e = 0; e < ir.n_elems; ++e)
+        if (ir.kind[e] == CSIM_L) termIsOne[static_cast<std::size_t>(ap.termBase[static_cast<std::size_t>(e)] + T_L_ONE)] = 1;
+
+    // ---- abstract matrix [row][col], col N = rhs
+    std::vector<std::vector<Kind>> M(static_cast<std::size_t>(N), std::vector<Kind>(static_cast<std::size_t>(N + 1)));
+    auto kindOf = [&](const int32_t* con, int n) {
+        Kind r;
+        if (n == 0) return r;
+        bool allConst = true;
+        double acc = 0.0;
+        for (int c = 0; c < n; ++c) {
+            const int t = con[c] >> 1;
+            if (!termIsOne[static_cast<std::size_t>(t)]) { allConst = false; break; }
+            acc = acc + ((con[c] & 1) ? -1.0 : 1.0);
+        }
+        if (!allConst) { r.k = Kind::DYN; return r; }
+        if (acc != 0.0) { r.k = Kind::CONST; r.c = acc; }
+        return r;
+    };
+    for (int n = 0; n < g.nnzG(); ++n) {
+        const int pos = g.gPos[static_cast<std::size_t>(n)];
+        M[static_cast<std::size_t>(pos / LD)][static_cast<std::size_t>(pos % LD)] =
+            kindOf(&g.gCon[static_cast<std::size_t>(g.gPtr[static_cast<std::size_t>(n)])],
+                   g.gPtr[static_cast<std::size_t>(n + 1)] - g.gPtr[static_cast<std::size_t>(n)]);
+    }
+    for (int n = 0; n < g.nnzI(); ++n)
+        M[static_cast<std::size_t>(g.iRow[static_cast<std::size_t>(n)])][static_cast<std::size_t>(N)] =
+            kindOf(&g.iCon[static_cast<std::size_t>(g.iPtr[static_cast<std::size_t>(n)])],
+                   g.iPtr[static_cast<std::size_t>(n + 1)] - g.iPtr[static_cast<std::size_t>(n)]);
+
+    // ---- placement: replay the swaps
+    std::vector<int> cur(static_cast<std::size_t>(N));
+    for (int i = 0; i < N; ++i) cur[static_cast<std::size_t>(i)] = i;
+    gp.finalPos.assign(static_cast<std::size_t>(N), -1);
+    gp.rowAtPos.assign(static_cast<std::size_t>(N), -1);
+    {
+        std::vector<int> c2 = cur;
+        for (int k = 0; k < N; ++k) {
+            const int p = sch.pivotPos[static_cast<std::size_t>(k)];
+            if (p < k || p >= N) return false;
+            std::swap(c2[static_cast<std::size_t>(k)], c2[static_cast<std::size_t>(p)]);
+            gp.finalPos[static_cast<std::size_t>(c2[static_cast<std::size_t>(k)])] = k;
+            gp.rowAtPos[static_cast<std::size_t>(k)] = c2[static_cast<std::size_t>(k)];
+        }
+    }
+    auto slotOf = [&](int row) { return gp.finalPos[static_cast<std::size_t>(row)] / kGroupLanes; };
+    auto laneOf = [&](int row) { return gp.finalPos[static_cast<std::size_t>(row)] % kGroupLanes; };
+
+    gp.classLive.assign(static_cast<std::size_t>(S), std::vector<uint8_t>(static_cast<std::size_t>(N + 1), 0));
+    auto markLive = [&]() {
+        for (int r = 0; r < N; ++r)
+            for (int c = 0; c <= N; ++c)
+                if (!M[static_cast<std::size_t>(r)][static_cast<std::size_t>(c)].zero())
+                    gp.classLive[static_cast<std::size_t>(slotOf(r))][static_cast<std::size_t>(c)] = 1;
+    };
+    markLive();
+
+    // ---- symbolic elimination with the recorded pivots (solver.hpp:46-77)
+    gp.cols.resize(static_cast<std::size_t>(N));
+    for (int k = 0; k < N; ++k) {
+        GroupPlan::Column& col = gp.cols[static_cast<std::size_t>(k)];
+        const int p = sch.pivotPos[static_cast<std::size_t>(k)];
+        const int P = cur[static_cast<std::size_t>(p)];
+        const Kind pv = M[static_cast<std::size_t>(P)][static_cast<std::size_t>(k)];
+        if (pv.zero()) col.zeroPivot = true;
+        col.pivotConst = pv.k == Kind::CONST;
+        col.pivotValue = pv.c;
+        // the reference picks the FIRST row attaining the column maximum (solver.hpp:48-56): rows before the
+        // scheduled one must be strictly smaller, rows after it not larger; tiny pivot fails (:58-61)
+        std::map<std::pair<int, bool>, unsigned> groups;
+        if (!col.zeroPivot) {
+            if (col.pivotConst && std::fabs(pv.c) < ir.k.lu_eps) col.contradiction = true;
+            for (int i = k; i < N; ++i) {
+                if (i == p) continue;
+                const int R = cur[static_cast<std::size_t>(i)];
+                const Kind a = M[static_cast<std::size_t>(R)][static_cast<std::size_t>(k)];
+                if (a.zero()) continue;
+                const bool strict = i < p;
+                if (a.k == Kind::CONST && pv.k == Kind::CONST) {
+                    const bool ok = strict ? std::fabs(pv.c) > std::fabs(a.c) : std::fabs(pv.c) >= std::fabs(a.c);
+                    if (!ok) col.contradiction = true;
+                    continue;
+                }
+                groups[{slotOf(R), strict}] |= 1u << laneOf(R);
+            }
+        }
+        for (const auto& kv : groups) col.checks.push_back({kv.first.first, kv.first.second, kv.second});
+        gp.nCmp += static_cast<int>(col.checks.size()) + (col.pivotConst ? 0 : 1);
+        if (!col.pivotConst && !col.zeroPivot) ++gp.nRecip;
+        std::swap(cur[static_cast<std::size_t>(k)], cur[static_cast<std::size_t>(p)]);
+        // pivot-row entries right of the diagonal
+        for (int j = k + 1; j <= N; ++j) {
+            const Kind u = M[static_cast<std::size_t>(P)][static_cast<std::size_t>(j)];
+            if (u.zero()) continue;
+            col.u.push_back({j, u.k == Kind::CONST, u.c});
+            if (u.k != Kind::CONST) ++gp.nBcast;
+        }
+        ++gp.nBcast;                                     // the pivot itself
+        std::vector<char> slotHasL(static_cast<std::size_t>(S), 0);
+        for (int i = k + 1; i < N; ++i) {
+            const int R = cur[static_cast<std::size_t>(i)];
+            Kind& a = M[static_cast<std::size_t>(R)][static_cast<std::size_t>(k)];
+            if (a.zero()) continue;
+            slotHasL[static_cast<std::size_t>(slotOf(R))] = 1;
+            Kind f;                                                  // multiplier a / pivot (solver.hpp:71)
+            if (a.k == Kind::CONST && pv.k == Kind::CONST) { f.k = Kind::CONST; f.c = a.c * (1.0 / pv.c); }
+            else f.k = Kind::DYN;
+            for (const GroupPlan::UEntry& u : col.u) {
+                Kind& t = M[static_cast<std::size_t>(R)][static_cast<std::size_t>(u.j)];
+                if (f.k == Kind::CONST && u.isConst && t.k != Kind::DYN) {
+                    const double v = (t.k == Kind::CONST ? t.c : 0.0) - f.c * u.c;
+                    t.k = v == 0.0 ? Kind::ZERO : Kind::CONST;
+                    t.c = v;
+                    // a value that cancels exactly in the generator still occupies its register class
+                    gp.classLive[static_cast<std::size_t>(slotOf(R))][static_cast<std::size_t>(u.j)] = 1;
+                } else {
+                    t.k = Kind::DYN;
+                }
+            }
+            a = Kind();                                              // below the diagonal: never read again
+        }
+        for (int s = 0; s < S; ++s)
+            if (slotHasL[static_cast<std::size_t>(s)]) {
+                col.lSlots.push_back(s);
+                ++gp.nMul;
+                gp.nFma += static_cast<int>(col.u.size());
+            }
+        if (!col.lSlots.empty() && std::find(col.lSlots.begin(), col.lSlots.end(), k / kGroupLanes) != col.lSlots.end()) ++gp.nMul;
+        markLive();
+    }
+
+    // ---- back substitution (solver.hpp:116-128), column-wise
+    gp.backSlots.assign(static_cast<std::size_t>(N), {});
+    for (int j = 0; j < N; ++j) {
+        std::vector<char> has(static_cast<std::size_t>(S), 0);
+        for (int i = 0; i < j; ++i) {
+            const int R = gp.rowAtPos[static_cast<std::size_t>(i)];
+            if (!M[static_cast<std::size_t>(R)][static_cast<std::size_t>(j)].zero()) has[static_cast<std::size_t>(i / kGroupLanes)] = 1;
+        }
+        for (int s = 0; s < S; ++s)
+            if (has[static_cast<std::size_t>(s)]) { gp.backSlots[static_cast<std::size_t>(j)].push_back(s); ++gp.nFma; }
+        gp.nMul += 1;
+        gp.nBcast += 1;
+    }
+
+    // ---- assembly tables
+    // matrix cells: terms that are constant over a launch, in stamping order; MOS terms go to staging rows
+    std::map<std::pair<int, int>, int> classIndex;                      // (s, j) -> index in gClasses
+    std::vector<std::vector<int32_t>> cellCon;                           // [class*16 + lane]
+    std::map<std::tuple<int, int, int>, int> stageIndex;                 // (s, j, round) -> staging row
+    gp.mosDest.assign(gp.mosElem.size(), {{-1, -1, -1, -1, -1, -1, -1, -1}});
+    auto addCell = [&](int row, int colj, const int32_t* con, int n, bool rhs) {
+        const int s = slotOf(row), lane = laneOf(row);
+        int round = 0;
+        for (int c = 0; c < n; ++c) {
+            const int t = con[c] >> 1;
+            const bool neg = (con[c] & 1) != 0;
+            const int m = mosOfTerm[static_cast<std::size_t>(t)];
+            if (m >= 0) {
+                const auto key = std::make_tuple(s, colj, round++);
+                auto it = stageIndex.find(key);
+                if (it == stageIndex.end()) {
+                    it = stageIndex.emplace(key, static_cast<int>(gp.stageRows.size())).first;
+                    gp.stageRows.push_back({s, colj});
+                }
+                const int kind = mosStampKind(offOfTerm[static_cast<std::size_t>(t)], neg);
+                gp.mosDest[static_cast<std::size_t>(m)][static_cast<std::size_t>(kind)] = it->second * kGroupLanes + lane;
+                continue;
+            }
+            if (rhs) continue;                                           // handled below (per-step gather)
+            auto ci = classIndex.find({s, colj});
+            if (ci == classIndex.end()) {
+                ci = classIndex.emplace(std::make_pair(s, colj), static_cast<int>(gp.gClasses.size())).first;
+                gp.gClasses.push_back({s, colj});
+                cellCon.resize(gp.gClasses.size() * kGroupLanes);
+            }
+            cellCon[static_cast<std::size_t>(ci->second * kGroupLanes + lane)].push_back(con[c]);
+        }
+    };
+    for (int n = 0; n < g.nnzG(); ++n) {
+        const int pos = g.gPos[static_cast<std::size_t>(n)];
+        addCell(pos / LD, pos % LD, &g.gCon[static_cast<std::size_t>(g.gPtr[static_cast<std::size_t>(n)])],
+                g.gPtr[static_cast<std::size_t>(n + 1)] - g.gPtr[static_cast<std::size_t>(n)], false);
+    }
+    std::vector<std::vector<int32_t>> rhsCon(static_cast<std::size_t>(S * kGroupLanes));
+    for (int n = 0; n < g.nnzI(); ++n) {
+        const int row = g.iRow[static_cast<std::size_t>(n)];
+        const int32_t* con = &g.iCon[static_cast<std::size_t>(g.iPtr[static_cast<std::size_t>(n)])];
+        const int cnt = g.iPtr[static_cast<std::size_t>(n + 1)] - g.iPtr[static_cast<std::size_t>(n)];
+        addCell(row, N, con, cnt, true);
+        for (int c = 0; c < cnt; ++c)
+            if (mosOfTerm[static_cast<std::size_t>(con[c] >> 1)] < 0)
+                rhsCon[static_cast<std::size_t>(slotOf(row) * kGroupLanes + laneOf(row))].push_back(con[c]);
+    }
+    // staging rows are added in the order (class, round): sort them so, and remap
+    {
+        std::vector<int> order(gp.stageRows.size());
+        for (std::size_t i = 0; i < order.size(); ++i) order[i] = static_cast<int>(i);
+        std::vector<std::tuple<int, int, int>> keys(gp.stageRows.size());
+        for (const auto& kv : stageIndex) keys[static_cast<std::size_t>(kv.second)] = kv.first;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return keys[static_cast<std::size_t>(a)] < keys[static_cast<std::size_t>(b)]; });
+        std::vector<int> newOf(order.size());
+        std::vector<GroupPlan::StageRow> rows(order.size());
+        for (std::size_t i = 0; i < order.size(); ++i) { newOf[static_cast<std::size_t>(order[i])] = static_cast<int>(i); rows[i] = gp.stageRows[static_cast<std::size_t>(order[i])]; }
+        gp.stageRows = rows;
+        for (auto& d : gp.mosDest)
+            for (int& cell : d)
+                if (cell >= 0) cell = newOf[static_cast<std::size_t>(cell / kGroupLanes)] * kGroupLanes + cell % kGroupLanes;
+    }
+    gp.gCellPtr.assign(1, 0);
+    for (const auto& c : cellCon) {
+        gp.gCellCon.insert(gp.gCellCon.end(), c.begin(), c.end());
+        gp.gCellPtr.push_back(static_cast<int32_t>(gp.gCellCon.size()));
+    }
+    gp.iCellPtr.assign(1, 0);
+    for (const auto& c : rhsCon) {
+        gp.iCellCon.insert(gp.iCellCon.end(), c.begin(), c.end());
+        gp.iCellPtr.push_back(static_cast<int32_t>(gp.iCellCon.size()));
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- interpreter
+void interpretGroupPlan(const GroupPlan& gp, const AssemblyPlan& ap, const csim_ir& ir, const double* T, double eps,
+                        double* x, bool* violated)
+{
+    (void)ir;
+    const int N = gp.N, S = gp.S, G = kGroupLanes;
+    // registers a[s][j][lane]
+    std::vector<double> a(static_cast<std::size_t>(S) * (N + 1) * G, 0.0);
+    auto A = [&](int s, int j, int lane) -> double& { return a[(static_cast<std::size_t>(s) * (N + 1) + j) * G + lane]; };
+    // (a) launch/step-constant parts
+    for (std::size_t c = 0; c < gp.gClasses.size(); ++c)
+        for (int lane = 0; lane < G; ++lane) {
+            double acc = 0.0;
+            for (int t = gp.gCellPtr[c * G + lane]; t < gp.gCellPtr[c * G + lane + 1]; ++t) {
+                const int con = gp.gCellCon[static_cast<std::size_t>(t)];
+                acc = (con & 1) ? acc - T[con >> 1] : acc + T[con >> 1];
+            }
+            A(gp.gClasses[c].s, gp.gClasses[c].j, lane) = acc;
+        }
+    for (int s = 0; s < S; ++s)
+        for (int lane = 0; lane < G; ++lane) {
+            double acc = 0.0;
+            for (int t = gp.iCellPtr[static_cast<std::size_t>(s * G + lane)]; t < gp.iCellPtr[static_cast<std::size_t>(s * G + lane + 1)]; ++t) {
+                const int con = gp.iCellCon[static_cast<std::size_t>(t)];
+                acc = (con & 1) ? acc - T[con >> 1] : acc + T[con >> 1];
+            }
+            A(s, N, lane) = acc;
+        }
+    // (b) MOS staging: lane m scatters, owners add row by row
+    std::vector<double> stage(gp.stageRows.size() * G, 0.0);
+    for (std::size_t m = 0; m < gp.mosElem.size(); ++m) {
+        const int tb = ap.termBase[static_cast<std::size_t>(gp.mosElem[m])];
+        const double gd = T[tb + T_M_GD], gg = T[tb + T_M_GG], gs = T[tb + T_M_GS], cst = T[tb + T_M_CST];
+        const double val[8] = {gd, gg, gs, -cst, -gd, -gg, -gs, cst};
+        for (int kd = 0; kd < 8; ++kd)
+            if (gp.mosDest[m][static_cast<std::size_t>(kd)] >= 0) stage[static_cast<std::size_t>(gp.mosDest[m][static_cast<std::size_t>(kd)])] = val[kd];
+    }
+    for (std::size_t r = 0; r < gp.stageRows.size(); ++r)
+        for (int lane = 0; lane < G; ++lane) A(gp.stageRows[r].s, gp.stageRows[r].j, lane) += stage[r * G + lane];
+
+    bool bad = false;
+    for (int k = 0; k < N; ++k) {
+        const GroupPlan::Column& col = gp.cols[static_cast<std::size_t>(k)];
+        const int sk = k / G, lk = k % G;
+        if (col.zeroPivot || col.contradiction) { bad = true; continue; }
+        const double pb = A(sk, k, lk);                                   // broadcast
+        if (!col.pivotConst && !(std::fabs(pb) >= eps)) bad = true;
+        for (const GroupPlan::Check& c : col.checks)
+            for (int lane = 0; lane < G; ++lane)
+                if (c.laneMask & (1u << lane)) {
+                    const double v = std::fabs(A(c.slot, k, lane));
+                    if (!(c.strict ? std::fabs(pb) > v : std::fabs(pb) >= v)) bad = true;
+                }
+        const double r = 1.0 / pb;
+        for (int s : col.lSlots)
+            for (int lane = 0; lane < G; ++lane) {
+                const double mask = (s == sk) ? (lane > lk ? 1.0 : 0.0) : 1.0;
+                const double f = A(s, k, lane) * (r * mask);
+                for (const GroupPlan::UEntry& u : col.u) {
+                    const double ub = u.isConst ? u.c : A(sk, u.j, lk);
+                    A(s, u.j, lane) = A(s, u.j, lane) - f * ub;
+                }
+            }
+    }
+    for (int j = N - 1; j >= 0; --j) {
+        const GroupPlan::Column& col = gp.cols[static_cast<std::size_t>(j)];
+        const int sj = j / G, lj = j % G;
+        const double piv = A(sj, j, lj);
+        const double xj = (col.zeroPivot || col.contradiction) ? 0.0 : A(sj, N, lj) * (1.0 / piv);
+        x[j] = xj;
+        for (int s : gp.backSlots[static_cast<std::size_t>(j)])
+            for (int lane = 0; lane < G; ++lane) A(s, N, lane) = A(s, N, lane) - A(s, j, lane) * xj;
+    }
+    if (violated) *violated = bad;
+}
+
+} // namespace csim
