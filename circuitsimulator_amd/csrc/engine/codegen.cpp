@@ -1,6 +1,7 @@
 // codegen.cpp -- see codegen.hpp.  Symbolic execution of stamp + pivoted LU +
 // substitution over {zero, exact constant, run-time value}; emits HIP source.
 #include "codegen.hpp"
+#include "group_plan.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -1049,6 +1050,13 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     }
     const bool haveDc = ldsDc >= 0;
 
+    // sixteen lanes per instance (group_plan.hpp): the first (most frequent) schedule only; any other
+    // sequence is a violation there and goes through the hybrid stepping
+    GroupPlan groupPlan;
+    const std::string groupSrc = emitGroupKernel(ir, ap, set.alts[0], gopt, &groupPlan);
+    const bool haveGroup = !groupSrc.empty();
+    src << groupSrc;
+
     char hbuf[32];
     std::snprintf(hbuf, sizeof hbuf, "0x%016llxull", static_cast<unsigned long long>(hash));
     char tbuf[32];
@@ -1059,7 +1067,14 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "extern \"C\" const char* csim_sched_info(void) { return \"" << label << " N=" << N << " schedule="
         << set.str() << " lds_doubles_per_lane=" << ldsLean << "/" << ldsRich
         << " ops_per_solve: fma=" << leanStats.nFma << " mul=" << leanStats.nMul << " addsub=" << leanStats.nAddSub
-        << " recip=" << leanStats.nRecip << " cmp=" << leanStats.nCmp << "\"; }\n"
+        << " recip=" << leanStats.nRecip << " cmp=" << leanStats.nCmp;
+    if (haveGroup)
+        src << " group16_wave_ops_per_solve: bcast=" << groupPlan.nBcast << " fma=" << groupPlan.nFma << " mul=" << groupPlan.nMul
+            << " cmp=" << groupPlan.nCmp << " recip=" << groupPlan.nRecip;
+    src << "\"; }\n"
+        << "// 16 when this library also carries csim_tran_group_kernel (sixteen lanes per instance, first schedule only)\n"
+        << "extern \"C\" int csim_sched_group_lanes(void) { return " << (haveGroup ? 16 : 0) << "; }\n";
+    src << ""
         << "// the recorded alternatives, [n_alts][N] pivot row positions (the engine hands them to the\n"
         << "// general kernel so that it can tell when an instance is back on a known sequence)\n"
         << "extern \"C\" const int* csim_sched_alts(int* nAlts, int* n)\n{\n    static const int table[] = {";
@@ -1094,6 +1109,12 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "    const unsigned waves = (unsigned)((B + 63) / 64);\n"
         << "    const bool rich = " << (haveRich ? "(variant == 2)" : "false") << ";\n"
         ;
+    if (haveGroup)
+        src << "    if (variant == 16) {\n"
+            << "        hipLaunchKernelGGL(csim_tran_group_kernel, dim3((unsigned)((B + 3) / 4)), dim3(64), 0, (hipStream_t)stream,\n"
+            << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
+            << "                           stepIters, fallback, done, violFlag);\n"
+            << "        return (int)hipGetLastError();\n    }\n";
     for (std::size_t k = 0; k < sweep.size(); ++k)
         src << "    if (variant == " << (10 + k) << ") { hipLaunchKernelGGL(csim_tran_sched_kernel_sweep" << k
             << ", dim3(waves), dim3(64), 0, (hipStream_t)stream, params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status, stepIters, fallback, done, violFlag); return (int)hipGetLastError(); }\n";

@@ -1,0 +1,492 @@
+// codegen_group.cpp -- HIP emitter of the sixteen-lanes-per-instance scheduled transient kernel
+// (plan and rationale: group_plan.hpp).  The emitted kernel has the parameters and the hand-over
+// protocol of the lane-per-instance kernel (codegen.cpp): fallback[], done[], violFlag.
+#include "group_plan.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <sstream>
+
+namespace csim {
+
+namespace {
+
+std::string lit(double x)
+{
+    char buf[64];
+    std::snprintf(buf, sizeof buf, "%a", x);
+    return std::string("(") + buf + ")";
+}
+
+std::string intArray(const std::string& name, const std::vector<int32_t>& v)
+{
+    std::ostringstream o;
+    o << "static __device__ const int " << name << "[" << (v.empty() ? 1 : v.size()) << "] = {";
+    if (v.empty()) o << "0";
+    for (std::size_t i = 0; i < v.size(); ++i) o << (i ? "," : "") << ((i % 32 == 31) ? "\n    " : "") << v[i];
+    o << "};\n";
+    return o.str();
+}
+
+// device code that does not depend on the circuit: element terms restated from the reference
+// (the general kernels' versions live in device_common.hpp; a generated library is self-contained)
+const char* kPrelude = R"GRP(
+// ================= sixteen lanes per instance: shared device code =================
+#define GRP_LANES 16
+// broadcast of one lane's double to its DPP row of 16 lanes (v_mov_b64_dpp row_newbcast)
+template <int L> __device__ __forceinline__ double grp_bc(double v)
+{
+    // bound_ctrl set: every lane has a source under row_newbcast, and the compiler then needs no
+    // initialising move for the destination (one v_mov_b64_dpp per broadcast)
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + L, 0xF, 0xF, true);
+}
+// sum over the 16 lanes of a row, result in every lane
+__device__ __forceinline__ double grp_sum16(double v)
+{
+    v += __builtin_amdgcn_update_dpp(0.0, v, 0x111, 0xF, 0xF, true);    // row_shr:1, zeros shifted in
+    v += __builtin_amdgcn_update_dpp(0.0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0.0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0.0, v, 0x118, 0xF, 0xF, true);
+    return grp_bc<15>(v);
+}
+__device__ __forceinline__ double grp_rcp_nr(double a)
+{
+    double r = __builtin_amdgcn_rcp(a);
+    r = fma(fma(-a, r, 1.0), r, r);
+    r = fma(fma(-a, r, 1.0), r, r);
+    return r;
+}
+// one wave per workgroup: LDS traffic of the wave is ordered by issue; this is the compiler fence
+__device__ __forceinline__ void grp_sync() { __syncthreads(); }
+
+// ordered sum of signed terms of one cell (plan.hpp: con = (term << 1) | negate)
+__device__ __forceinline__ double grp_gather(const double* T, const int* ptr, const int* con, int cell)
+{
+    double acc = 0.0;
+    for (int c = ptr[cell]; c < ptr[cell + 1]; ++c) {
+        const int k = con[c];
+        const double v = T[k >> 1];
+        acc = (k & 1) ? acc - v : acc + v;
+    }
+    return acc;
+}
+
+#pragma clang fp contract(off)
+__device__ __forceinline__ double grp_clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
+// SourceSpec::evalTran (include/sim.hpp:160-162) with TranWaveform::eval (:75-143): SIN, PULSE, PWL
+template <typename PGet>
+__device__ __forceinline__ double grp_source_tran(PGet P, int wave, int waveN, double t, double pi)
+{
+    double w = 0.0;
+    if (wave == GRP_WAVE_SIN) {
+        const double v0 = P(1), va = P(2), freq = P(3), td = P(4), phi = P(5);
+        if (t < td) w = v0;
+        else { const double tau = t - td; const double om = 2.0 * pi * freq; w = v0 + va * sin(om * tau + phi); }
+    } else if (wave == GRP_WAVE_PULSE) {
+        const double v1 = P(1), v2 = P(2), td = P(3), tr = P(4), tf = P(5), ton = P(6), per = P(7);
+        if (per <= 0.0) {
+            const double tau = t - td;
+            if (tau <= 0.0) w = v1;
+            else if (tau < tr) { const double k = grp_clamp01(tau / tr); w = v1 + k * (v2 - v1); }
+            else if (tau < tr + ton) w = v2;
+            else { const double tfall = tau - (tr + ton); const double k = grp_clamp01(tfall / tf); w = v2 + k * (v1 - v2); }
+        } else if (t < td) {
+            w = v1;
+        } else {
+            double tau = fmod(t - td, per);
+            if (tau < 0.0) tau += per;
+            if (tau < tr) { const double k = grp_clamp01(tau / tr); w = v1 + (v2 - v1) * k; }
+            else if (tau < tr + ton) w = v2;
+            else if (tau < tr + ton + tf) { const double tfall = tau - (tr + ton); const double k = grp_clamp01(tfall / tf); w = v2 + (v1 - v2) * k; }
+            else w = v1;
+        }
+    } else if (wave == GRP_WAVE_PWL) {
+        const int n = waveN;
+        if (n <= 0) w = 0.0;
+        else if (t <= P(1)) w = P(1 + n);
+        else if (t >= P(n)) w = P(2 * n);
+        else {
+            w = P(2 * n);
+            for (int i = 0; i + 1 < n; ++i) {
+                const double ta = P(1 + i), tb = P(2 + i);
+                if (t > ta && t <= tb) {
+                    const double va = P(1 + n + i), vb = P(2 + n + i);
+                    const double k = (t - ta) / (tb - ta);
+                    w = va + (vb - va) * k;
+                    break;
+                }
+            }
+        }
+    }
+    return P(0) + w;
+}
+// Level-1 MOSFET linearisation, MosfetBase::stamp (src/element.cpp:207-274); p = +1 (NMOS) / -1 (PMOS).
+// Same operations as the reference, selects instead of branches, no contraction.
+__device__ __forceinline__ void grp_mos_eval(double p, double Vth, double K, double lambda, double offGds,
+                                             double Vd, double Vg, double Vs, double& gd, double& gg, double& gs, double& cst)
+{
+    const double Vgs = p * (Vg - Vs);
+    const double Vds = p * (Vd - Vs);
+    const double Vov = Vgs - Vth;
+    const bool on = (Vgs > Vth) && (Vds >= 0.0);
+    const bool tri = Vds < Vov;
+    const double Ids0 = on ? (tri ? K * (Vov * Vds - 0.5 * Vds * Vds) : 0.5 * K * Vov * Vov) : 0.0;
+    const double gds0 = on ? (tri ? K * (Vov - Vds) : 0.0) : offGds;
+    const double gm0 = on ? (tri ? K * Vds : K * Vov) : 0.0;
+    double factor = 1.0 + lambda * Vds;
+    if (factor < 0.0) factor = 0.0;
+    const double Ids = p * (Ids0 * factor);
+    gd = gds0 * factor + Ids0 * lambda;
+    gg = gm0 * factor;
+    gs = -(gd + gg);
+    cst = Ids - gd * Vd - gg * Vg - gs * Vs;
+}
+#pragma clang fp contract(fast)
+)GRP";
+
+} // namespace
+
+std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch,
+                            const GeneratorOptions& gopt, GroupPlan* planOut)
+{
+    (void)gopt;       // no scheduling barriers here: 270 registers, nothing spills, the scheduler may roam
+    GroupPlan gp;
+    if (!buildGroupPlan(ir, ap, sch, gp)) return std::string();
+    if (planOut) *planOut = gp;
+    const int N = gp.N, S = gp.S, G = kGroupLanes;
+    const csim_consts& K = ir.k;
+    const int NP = S * G;                                       // padded unknown count
+    const int nMos = static_cast<int>(gp.mosElem.size());
+    const int mosRounds = (nMos + G - 1) / G;
+    const int nStage = static_cast<int>(gp.stageRows.size());
+
+    // LDS carve-up per instance (doubles)
+    const int oXS = 0, oXP = oXS + NP + 1, oXR = oXP + NP + 1, oTT = oXR + NP, oST = oTT + ap.nTerms;
+    const int instDoubles = oST + (nStage + 1) * G;
+    if (instDoubles * 8 * 4 > 64 * 1024) return std::string();  // keep 2+ waves per CU possible; larger circuits: no group kernel
+
+    std::ostringstream o;
+    o << "#define GRP_WAVE_SIN " << CSIM_WAVE_SIN << "\n#define GRP_WAVE_PULSE " << CSIM_WAVE_PULSE << "\n#define GRP_WAVE_PWL " << CSIM_WAVE_PWL << "\n"
+      << kPrelude << "\n";
+
+    // ---- circuit tables
+    {
+        std::vector<int32_t> kind(ir.kind, ir.kind + ir.n_elems), eq(ir.eq, ir.eq + 4 * ir.n_elems),
+            branch(ir.branch_eq, ir.branch_eq + ir.n_elems), slot(ir.param_slot, ir.param_slot + ir.n_elems),
+            wave(ir.wave, ir.wave + ir.n_elems), waveN(ir.wave_n, ir.wave_n + ir.n_elems),
+            tbase(ap.termBase.begin(), ap.termBase.end());
+        o << intArray("grp_kind", kind) << intArray("grp_eq", eq) << intArray("grp_branch", branch)
+          << intArray("grp_slot", slot) << intArray("grp_wave", wave) << intArray("grp_waveN", waveN)
+          << intArray("grp_tbase", tbase)
+          << intArray("grp_gPtr", gp.gCellPtr) << intArray("grp_gCon", gp.gCellCon)
+          << intArray("grp_iPtr", gp.iCellPtr) << intArray("grp_iCon", gp.iCellCon);
+        std::vector<int32_t> mosTab(static_cast<std::size_t>(std::max(1, mosRounds) * G), -1), destTab(static_cast<std::size_t>(std::max(1, mosRounds) * G * 8), -1);
+        for (int m = 0; m < nMos; ++m) {
+            mosTab[static_cast<std::size_t>(m)] = gp.mosElem[static_cast<std::size_t>(m)];
+            for (int kd = 0; kd < 8; ++kd) destTab[static_cast<std::size_t>(m * 8 + kd)] = gp.mosDest[static_cast<std::size_t>(m)][static_cast<std::size_t>(kd)];
+        }
+        o << intArray("grp_mosElem", mosTab) << intArray("grp_mosDest", destTab);
+    }
+
+    o << "\n// One DPP row of 16 lanes = one circuit instance, 4 instances per wavefront (group_plan.hpp).\n"
+      << "// pivot schedule: " << (sch.str().empty() ? std::string("-") : sch.str()) << "\n"
+      << "extern \"C\" __global__ void __launch_bounds__(64)\n"
+      << "csim_tran_group_kernel(const double* __restrict__ params, int B, double dt, long long stepFirst,\n"
+      << "                       long long nSteps, const int* __restrict__ probeEq, int nProbe, int outStride,\n"
+      << "                       double* __restrict__ wave, double* __restrict__ xio, long long* __restrict__ iters,\n"
+      << "                       unsigned* __restrict__ status, int* __restrict__ stepIters,\n"
+      << "                       unsigned char* __restrict__ fallback, int* __restrict__ done,\n"
+      << "                       int* __restrict__ violFlag)\n{\n"
+      << "    __shared__ double lds[4 * " << instDoubles << "];\n"
+      << "    const int lane = threadIdx.x, g = lane & 15, q = lane >> 4;\n"
+      << "    const int b = blockIdx.x * 4 + q;\n"
+      << "    const bool inb = b < B;\n"
+      << "    const long long bb = inb ? b : B - 1;      // out-of-range groups shadow the last instance, never store\n"
+      << "    const long long SB = B;\n"
+      << "    if (!__any(inb && done[bb] < nSteps)) return;\n"
+      << "    double* const XS = lds + q * " << instDoubles << " + " << oXS << ";   // iterate; XS[" << NP << "] = 0 (ground)\n"
+      << "    double* const XP = lds + q * " << instDoubles << " + " << oXP << ";   // state at the start of the step (history, checkpoint)\n"
+      << "    double* const XR = lds + q * " << instDoubles << " + " << oXR << ";   // raw Newton solution\n"
+      << "    double* const TT = lds + q * " << instDoubles << " + " << oTT << ";   // element terms (plan.hpp)\n"
+      << "    double* const ST = lds + q * " << instDoubles << " + " << oST << ";   // MOSFET staging rows [row][16]; last row = dummy\n"
+      << "    const unsigned long long rowBits = 0xFFFFull << (16 * q);\n"
+      << "    auto P = [&](int slot) -> double { return params[(long long)slot * SB + bb]; };\n\n";
+
+    // ---- launch setup: zero staging, constants, terms
+    o << "    for (int i = g; i < " << (nStage + 1) * G << "; i += 16) ST[i] = 0.0;\n"
+      << "    for (int i = g; i < " << ap.nTerms << "; i += 16) TT[i] = 0.0;\n"
+      << "    for (int i = g; i < " << NP << "; i += 16) XR[i] = 0.0;\n"
+      << "    if (g == 0) { XS[" << NP << "] = 0.0; XP[" << NP << "] = 0.0; }\n"
+      << "    grp_sync();\n"
+      << "    bool badL = false;\n"
+      << "    for (int e = g; e < " << ir.n_elems << "; e += 16) {          // terms constant over the launch (tanalisis.cpp:59-80,294-341)\n"
+      << "        const int kind = grp_kind[e], s = grp_slot[e], tb = grp_tbase[e];\n"
+      << "        if (kind == " << CSIM_R << ") { const double R = P(s); TT[tb + " << T_R_G << "] = (R == 0.0) ? 0.0 : 1.0 / R; }\n"
+      << "        else if (kind == " << CSIM_C << ") { const double C = P(s); TT[tb + " << T_C_GC << "] = (C > 0.0 && dt > 0.0) ? C / dt : 0.0; }\n"
+      << "        else if (kind == " << CSIM_L << ") { const double L = P(s); badL = badL || !(L > 0.0); TT[tb + " << T_L_REQ << "] = L / dt; TT[tb + " << T_L_ONE << "] = 1.0; }\n"
+      << "        else if (kind == " << CSIM_NMOS << " || kind == " << CSIM_PMOS << ") {\n"
+      << "            const double Cj0 = P(s + 3), Ch = 0.5 * Cj0;\n"
+      << "            TT[tb + " << T_M_GCH << "] = (Ch > 0.0 && dt > 0.0) ? Ch / dt : 0.0;\n"
+      << "            TT[tb + " << T_M_GCF << "] = (Cj0 > 0.0 && dt > 0.0) ? Cj0 / dt : 0.0;\n"
+      << "        }\n"
+      << "    }\n"
+      << "    if (g == 0) { TT[" << ap.termOne << "] = 1.0; TT[" << ap.termGmin << "] = " << lit(K.tran_gmin) << "; }\n"
+      << "    // the inductor incidence is folded as the exact constant 1: needs L > 0 (tanalisis.cpp:296), else general kernel\n"
+      << "    bool viol = (__ballot(badL) & rowBits) != 0ull;\n"
+      << "    grp_sync();\n\n";
+
+    // per-lane 0/1 factors: rows of the slot being consumed that are still active at column k (g > k % 16)
+    // (formed arithmetically so that they live in vector registers, not as scalar lane masks)
+    for (int t = 0; t < G; ++t) o << "    const double mk" << t << " = fmin(fmax((double)(g - " << t << "), 0.0), 1.0);\n";
+    // launch-constant part of the matrix
+    o << "    // launch-constant part of every matrix class, terms summed in the reference's stamping order\n";
+    std::vector<std::vector<int>> classOf(static_cast<std::size_t>(S), std::vector<int>(static_cast<std::size_t>(N + 1), -1));
+    for (std::size_t c = 0; c < gp.gClasses.size(); ++c) {
+        classOf[static_cast<std::size_t>(gp.gClasses[c].s)][static_cast<std::size_t>(gp.gClasses[c].j)] = static_cast<int>(c);
+        o << "    const double c_" << gp.gClasses[c].s << "_" << gp.gClasses[c].j << " = grp_gather(TT, grp_gPtr, grp_gCon, " << c * G << " + g);\n";
+    }
+    // MOSFET lanes
+    for (int r = 0; r < std::max(1, mosRounds); ++r) {
+        const std::string R = std::to_string(r);
+        o << "    // MOSFET evaluated by this lane in round " << r << " (-1: none)\n"
+          << "    const int me" << R << " = grp_mosElem[" << r * G << " + g];\n"
+          << "    const int mq" << R << " = me" << R << " >= 0 ? me" << R << " : 0;\n"
+          << "    const int mD" << R << " = grp_eq[4 * mq" << R << "] >= 0 ? grp_eq[4 * mq" << R << "] : " << NP << ";\n"
+          << "    const int mG" << R << " = grp_eq[4 * mq" << R << " + 1] >= 0 ? grp_eq[4 * mq" << R << " + 1] : " << NP << ";\n"
+          << "    const int mS" << R << " = grp_eq[4 * mq" << R << " + 2] >= 0 ? grp_eq[4 * mq" << R << " + 2] : " << NP << ";\n"
+          << "    const double mp" << R << " = grp_kind[mq" << R << "] == " << CSIM_PMOS << " ? -1.0 : 1.0;\n"
+          << "    const double mvth" << R << " = P(grp_slot[mq" << R << "]), mK" << R << " = P(grp_slot[mq" << R << "] + 1), mlam" << R << " = P(grp_slot[mq" << R << "] + 2);\n";
+        for (int kd = 0; kd < 8; ++kd)
+            o << "    const int md" << R << "_" << kd << " = grp_mosDest[(" << r * G << " + g) * 8 + " << kd << "] >= 0 ? grp_mosDest[(" << r * G
+              << " + g) * 8 + " << kd << "] : " << nStage * G << " + g;\n";
+    }
+
+    // ---- state
+    o << "\n    // state: lane g keeps x[16 s + g]\n";
+    for (int s = 0; s < S; ++s) {
+        o << "    double xo" << s << " = (" << s * G << " + g < " << N << ") ? xio[(long long)(" << s * G << " + g) * SB + bb] : 0.0;\n"
+          << "    XS[" << s * G << " + g] = xo" << s << "; XP[" << s * G << " + g] = xo" << s << ";\n";
+    }
+    o << "    grp_sync();\n"
+      << "    unsigned st = inb ? status[bb] : 0u;\n"
+      << "    bool dead = !inb || (st & ST_TRAN_NONFINITE) != 0u;   // the reference would have thrown: stay stopped\n"
+      << "    long long itTotal = 0;\n"
+      << "    long long sdone = (inb && !dead) ? (long long)done[bb] : nSteps;\n"
+      << "    if (stepFirst == 0 && sdone == 0 && wave && inb)\n"
+      << "        for (int pq = g; pq < nProbe; pq += 16) wave[((long long)pq) * SB + b] = XS[probeEq[pq]];\n"
+      << "    int smin = (int)(sdone < nSteps ? sdone + 1 : nSteps + 1);\n"
+      << "    for (int m = 32; m >= 1; m >>= 1) { const int ot = __shfl_xor(smin, m); smin = ot < smin ? ot : smin; }\n"
+      << "    smin = __builtin_amdgcn_readfirstlane(smin);\n"
+      << "    for (long long s = smin; s <= nSteps; ++s) {\n"
+      << "        if (!__any(!dead && !viol && sdone < nSteps)) break;\n"
+      << "        const bool live = !dead && !viol && sdone + 1 == s;\n"
+      << "        const long long gstep = stepFirst + s;\n"
+      << "        const double tNow = (double)(int)gstep * dt;\n"
+      << "        if (live) {";
+    for (int s = 0; s < S; ++s) o << " XP[" << s * G << " + g] = xo" << s << ";";
+    o << " }\n"
+      << "        grp_sync();\n"
+      << "        // per-step terms: sources and history currents (tanalisis.cpp:77,308,337-341; sim.hpp:160-162)\n"
+      << "        for (int e = g; e < " << ir.n_elems << "; e += 16) {\n"
+      << "            const int kind = grp_kind[e], sl = grp_slot[e], tb = grp_tbase[e];\n"
+      << "            const int* eq4 = grp_eq + 4 * e;\n"
+      << "            if (kind == " << CSIM_V << " || kind == " << CSIM_I << ") {\n"
+      << "                TT[tb + " << T_SRC_VAL << "] = grp_source_tran([&](int i) { return P(sl + i); }, grp_wave[e], grp_waveN[e], tNow, " << lit(K.pi) << ");\n"
+      << "            } else if (kind == " << CSIM_C << ") {\n"
+      << "                const double vPrev = XP[eq4[0] >= 0 ? eq4[0] : " << NP << "] - XP[eq4[1] >= 0 ? eq4[1] : " << NP << "];\n"
+      << "                TT[tb + " << T_C_IH << "] = -TT[tb + " << T_C_GC << "] * vPrev;\n"
+      << "            } else if (kind == " << CSIM_L << ") {\n"
+      << "                const int kb = grp_branch[e];\n"
+      << "                TT[tb + " << T_L_VH << "] = -TT[tb + " << T_L_REQ << "] * XP[(kb >= 0 && kb < " << N << ") ? kb : " << NP << "];\n"
+      << "            } else if (kind == " << CSIM_NMOS << " || kind == " << CSIM_PMOS << ") {\n"
+      << "                const double vD = XP[eq4[0] >= 0 ? eq4[0] : " << NP << "], vG = XP[eq4[1] >= 0 ? eq4[1] : " << NP << "];\n"
+      << "                const double vS = XP[eq4[2] >= 0 ? eq4[2] : " << NP << "], vB = XP[eq4[3] >= 0 ? eq4[3] : " << NP << "];\n"
+      << "                const double gh = TT[tb + " << T_M_GCH << "], gf = TT[tb + " << T_M_GCF << "];\n"
+      << "                TT[tb + " << T_M_IHGS << "] = -gh * (vG - vS);\n"
+      << "                TT[tb + " << T_M_IHGD << "] = -gh * (vG - vD);\n"
+      << "                TT[tb + " << T_M_IHSB << "] = -gf * (vS - vB);\n"
+      << "                TT[tb + " << T_M_IHDB << "] = -gf * (vD - vB);\n"
+      << "            }\n"
+      << "        }\n"
+      << "        grp_sync();\n";
+    for (int s = 0; s < S; ++s)
+        o << "        const double cb" << s << " = grp_gather(TT, grp_iPtr, grp_iCon, " << s * G << " + g);   // right-hand side without the MOSFET terms\n";
+
+    const int slowIters = slowStepIters(K.tran_tol, K.tran_alpha, K.tran_max_iters);
+    const std::string in = "            ";
+    o << "        bool active = live;\n"
+      << "        int it = 0;\n"
+      << "        for (int iter = 0; iter < " << K.tran_max_iters << "; ++iter) {\n"
+      << "            if (!__any(active)) break;\n";
+    // ---- MOSFET evaluation + scatter
+    for (int r = 0; r < mosRounds; ++r) {
+        const std::string R = std::to_string(r);
+        o << in << "{   // MOSFET channel at the iterate (element.cpp:207-274), lane m of the group evaluates MOSFET " << r * G << " + m\n"
+          << in << "    double gd, gg, gs, cst;\n"
+          << in << "    grp_mos_eval(mp" << R << ", mvth" << R << ", mK" << R << ", mlam" << R << ", " << lit(K.mos_off_gds)
+          << ", XS[mD" << R << "], XS[mG" << R << "], XS[mS" << R << "], gd, gg, gs, cst);\n"
+          << in << "    if (me" << R << " >= 0) {\n"
+          << in << "        ST[md" << R << "_0] = gd; ST[md" << R << "_1] = gg; ST[md" << R << "_2] = gs; ST[md" << R << "_3] = -cst;\n"
+          << in << "        ST[md" << R << "_4] = -gd; ST[md" << R << "_5] = -gg; ST[md" << R << "_6] = -gs; ST[md" << R << "_7] = cst;\n"
+          << in << "    }\n"
+          << in << "}\n";
+    }
+    o << in << "grp_sync();\n";
+
+    // ---- assembly: class registers
+    o << in << "// assembly: (terms constant within the step) + (MOSFET terms from the staging rows, in stamping order)\n";
+    std::vector<std::vector<char>> declared(static_cast<std::size_t>(S), std::vector<char>(static_cast<std::size_t>(N + 1), 0));
+    for (int s = 0; s < S; ++s)
+        for (int j = 0; j <= N; ++j) {
+            if (!gp.classLive[static_cast<std::size_t>(s)][static_cast<std::size_t>(j)]) continue;
+            declared[static_cast<std::size_t>(s)][static_cast<std::size_t>(j)] = 1;
+            std::string init = "0.0";
+            if (j == N) init = "cb" + std::to_string(s);
+            else if (classOf[static_cast<std::size_t>(s)][static_cast<std::size_t>(j)] >= 0) init = "c_" + std::to_string(s) + "_" + std::to_string(j);
+            o << in << "double a_" << s << "_" << j << " = " << init << ";\n";
+        }
+    for (int r = 0; r < nStage; ++r) {
+        const GroupPlan::StageRow& sr = gp.stageRows[static_cast<std::size_t>(r)];
+        if (!declared[static_cast<std::size_t>(sr.s)][static_cast<std::size_t>(sr.j)]) return std::string();   // cannot happen: a staged cell is live
+        o << in << "a_" << sr.s << "_" << sr.j << " += ST[" << r * G << " + g];\n";
+    }
+
+    // ---- elimination
+    o << in << "int bad = 0;   // column + 1 of a failed pivot check on this lane's rows\n";
+    std::vector<std::string> rinv(static_cast<std::size_t>(N));
+    for (int k = 0; k < N; ++k) {
+        const GroupPlan::Column& col = gp.cols[static_cast<std::size_t>(k)];
+        const int sk = k / G, lk = k % G;
+        const std::string ak = "a_" + std::to_string(sk) + "_" + std::to_string(k);
+        o << in << "// column " << k << ": pivot row = lane " << lk << ", slot " << sk << "\n";
+        if (col.zeroPivot || col.contradiction) {
+            o << in << "bad = " << (k + 1) << ";   // scheduled pivot is a structural zero / contradicts exact constants\n";
+            rinv[static_cast<std::size_t>(k)] = "0.0";
+            continue;
+        }
+        std::string absP;
+        if (col.pivotConst) {
+            absP = lit(std::fabs(col.pivotValue));
+            rinv[static_cast<std::size_t>(k)] = lit(1.0 / col.pivotValue);
+        } else {
+            o << in << "const double pb" << k << " = grp_bc<" << lk << ">(" << ak << ");\n";
+            absP = "fabs(pb" + std::to_string(k) + ")";
+            o << in << "bad = (" << absP << " >= " << lit(K.lu_eps) << ") ? bad : " << (k + 1) << ";\n";
+        }
+        // Candidates (solver.hpp:48-56).  Every lane is compared: rows that are no candidates hold an exact
+        // zero in column k (structural zero) or are finished rows of the slot being consumed, which the 0/1
+        // factor mk removes.  |pivot| >= |a| must hold for all of them; rows that come BEFORE the scheduled
+        // row in the reference's scan must also differ from it (first maximum wins a tie).  Failures are
+        // recorded per lane as the column number + 1 (a select per test: no scalar masks to keep alive).
+        {
+            std::vector<unsigned> strictOf(static_cast<std::size_t>(S), 0u), anyOf(static_cast<std::size_t>(S), 0u);
+            for (const GroupPlan::Check& c : col.checks) {
+                anyOf[static_cast<std::size_t>(c.slot)] |= c.laneMask;
+                if (c.strict) strictOf[static_cast<std::size_t>(c.slot)] |= c.laneMask;
+            }
+            for (int s = 0; s < S; ++s) {
+                if (!anyOf[static_cast<std::size_t>(s)]) continue;
+                const std::string thr = "th" + std::to_string(k) + "_" + std::to_string(s);
+                o << in << "const double " << thr << " = fabs(a_" << s << "_" << k << ")" << (s == sk ? " * mk" + std::to_string(lk) : std::string()) << ";\n"
+                  << in << "bad = (" << absP << " >= " << thr << ") ? bad : " << (k + 1) << ";\n";
+                if (strictOf[static_cast<std::size_t>(s)]) {
+                    char m[16];
+                    std::snprintf(m, sizeof m, "0x%04x", strictOf[static_cast<std::size_t>(s)] & 0xFFFFu);
+                    o << in << "bad = (" << absP << " == " << thr << " && ((" << m << " >> g) & 1)) ? " << (k + 1) << " : bad;\n";
+                }
+            }
+        }
+        if (!col.pivotConst) {
+            o << in << "const double r" << k << " = grp_rcp_nr(pb" << k << ");\n";
+            rinv[static_cast<std::size_t>(k)] = "r" + std::to_string(k);
+        }
+        if (col.lSlots.empty()) continue;
+        // multipliers (solver.hpp:71); finished rows of the slot being consumed get an exact 0
+        for (int s : col.lSlots) {
+            const std::string as = "a_" + std::to_string(s) + "_" + std::to_string(k);
+            std::string e;
+            const bool masked = s == sk;
+            if (col.pivotConst) {
+                const double rc = 1.0 / col.pivotValue;
+                if (rc == 1.0) e = masked ? as + " * mk" + std::to_string(lk) : as;
+                else if (rc == -1.0) e = masked ? "-(" + as + " * mk" + std::to_string(lk) + ")" : "-" + as;
+                else e = masked ? as + " * (" + lit(rc) + " * mk" + std::to_string(lk) + ")" : as + " * " + lit(rc);
+            } else {
+                e = masked ? as + " * (r" + std::to_string(k) + " * mk" + std::to_string(lk) + ")" : as + " * r" + std::to_string(k);
+            }
+            o << in << "const double f" << k << "_" << s << " = " << e << ";\n";
+        }
+        for (const GroupPlan::UEntry& u : col.u) {
+            std::string ub;
+            if (u.isConst) ub = lit(u.c);
+            else {
+                o << in << "const double u" << k << "_" << u.j << " = grp_bc<" << lk << ">(a_" << sk << "_" << u.j << ");\n";
+                ub = "u" + std::to_string(k) + "_" + std::to_string(u.j);
+            }
+            for (int s : col.lSlots) {
+                const std::string t = "a_" + std::to_string(s) + "_" + std::to_string(u.j);
+                if (!declared[static_cast<std::size_t>(s)][static_cast<std::size_t>(u.j)]) return std::string();   // fill into a class the plan did not mark
+                const std::string f = "f" + std::to_string(k) + "_" + std::to_string(s);
+                if (u.isConst && u.c == 1.0) o << in << t << " = " << t << " - " << f << ";\n";
+                else if (u.isConst && u.c == -1.0) o << in << t << " = " << t << " + " << f << ";\n";
+                else o << in << t << " = " << t << " - " << f << " * " << ub << ";\n";
+            }
+        }
+    }
+
+    // ---- back substitution, column-wise (solver.hpp:116-128)
+    o << in << "// back substitution: x_j is formed in lane j % 16, broadcast, and subtracted from the rows above\n";
+    for (int j = N - 1; j >= 0; --j) {
+        const int sj = j / G, lj = j % G;
+        o << in << "const double xb" << j << " = grp_bc<" << lj << ">(a_" << sj << "_" << N << " * " << rinv[static_cast<std::size_t>(j)] << ");\n"
+          << in << "XR[" << j << "] = xb" << j << ";\n";
+        for (int s : gp.backSlots[static_cast<std::size_t>(j)])
+            o << in << "a_" << s << "_" << N << " = a_" << s << "_" << N << " - a_" << s << "_" << j << " * xb" << j << ";\n";
+    }
+    o << in << "grp_sync();\n";
+
+    // ---- damped update, norm, convergence (tanalisis.cpp:360-376)
+    o << in << "double ss = 0.0;\n";
+    for (int s = 0; s < S; ++s)
+        o << in << "const double xn" << s << " = xo" << s << " + " << lit(K.tran_alpha) << " * (XR[" << s * G << " + g] - xo" << s << ");\n"
+          << in << "{ const double d = xn" << s << " - xo" << s << "; ss += d * d; }\n";
+    o << in << "ss = grp_sum16(ss);\n"
+      << in << "const double err = sqrt(ss);\n"
+      << in << "const bool pv = (__ballot(bad != 0) & rowBits) != 0ull;\n"
+      << in << "if (active) {\n"
+      << in << "    if (pv || !(ss < 1.0e300)) { viol = true; active = false; }\n"
+      << in << "    else {\n"
+      << in << "        ++it;\n";
+    for (int s = 0; s < S; ++s) o << in << "        xo" << s << " = xn" << s << "; XS[" << s * G << " + g] = xn" << s << ";\n";
+    o << in << "        if (err < " << lit(K.tran_tol) << ") active = false;\n"
+      << in << "        else if (iter >= " << (slowIters - 1) << ") { viol = true; active = false; }   // slow step: plan.hpp slowStepIters\n"
+      << in << "    }\n"
+      << in << "}\n"
+      << in << "grp_sync();\n"
+      << "        }\n"      // NR loop
+      << "        if (live && !viol) {\n"
+      << "            itTotal += it;\n"
+      << "            if (stepIters && g == 0) stepIters[(s - 1) * SB + b] = it;\n"
+      << "            if (wave && (gstep % outStride) == 0) {\n"
+      << "                const long long row = gstep / outStride;\n"
+      << "                for (int pq = g; pq < nProbe; pq += 16) wave[(row * nProbe + pq) * SB + b] = XS[probeEq[pq]];\n"
+      << "            }\n"
+      << "            sdone = s;\n"
+      << "        }\n"
+      << "    }\n\n"
+      << "    if (inb) {\n"
+      << "        // a violated instance hands the state at the START of the failing step to the general kernel\n";
+    for (int s = 0; s < S; ++s)
+        o << "        if (" << s * G << " + g < " << N << ") xio[(long long)(" << s * G << " + g) * SB + b] = viol ? XP[" << s * G << " + g] : xo" << s << ";\n";
+    o << "        if (g == 0) {\n"
+      << "            if (viol) { fallback[b] = 1; *violFlag = 1; }\n"
+      << "            iters[b] += itTotal;\n"
+      << "            status[b] |= st;\n"
+      << "            done[b] = (int)sdone;\n"
+      << "        }\n"
+      << "    }\n"
+      << "}\n\n";
+    return o.str();
+}
+
+} // namespace csim

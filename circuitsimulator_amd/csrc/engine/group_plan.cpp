@@ -103,6 +103,7 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
     auto laneOf = [&](int row) { return gp.finalPos[static_cast<std::size_t>(row)] % kGroupLanes; };
 
     gp.classLive.assign(static_cast<std::size_t>(S), std::vector<uint8_t>(static_cast<std::size_t>(N + 1), 0));
+    for (int s = 0; s < S; ++s) gp.classLive[static_cast<std::size_t>(s)][static_cast<std::size_t>(N)] = 1;   // right-hand sides always exist
     auto markLive = [&]() {
         for (int r = 0; r < N; ++r)
             for (int c = 0; c <= N; ++c)
