@@ -264,6 +264,46 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
             for (int& cell : d)
                 if (cell >= 0) cell = newOf[static_cast<std::size_t>(cell / kGroupLanes)] * kGroupLanes + cell % kGroupLanes;
     }
+    // ---- critical path of one solve (dependent-issue latency model: every VALU result is usable lat
+    // cycles after issue; the Newton-refined reciprocal is a chain of 1 + 4 operations)
+    {
+        const int lat = 8, latRcp = 5 * 8;
+        std::vector<std::vector<int>> t(static_cast<std::size_t>(S), std::vector<int>(static_cast<std::size_t>(N + 1), 0));
+        int worst = 0;
+        std::vector<int> tr(static_cast<std::size_t>(N), 0);
+        for (int k = 0; k < N; ++k) {
+            const GroupPlan::Column& col = gp.cols[static_cast<std::size_t>(k)];
+            const int sk = k / kGroupLanes;
+            int r = 0;
+            if (!col.pivotConst) r = t[static_cast<std::size_t>(sk)][static_cast<std::size_t>(k)] + lat + latRcp;
+            tr[static_cast<std::size_t>(k)] = r;
+            std::vector<int> tf(static_cast<std::size_t>(S), 0);
+            for (int s : col.lSlots) {
+                const int rr = (s == sk && !col.pivotConst) ? r + lat : r;      // r * mk
+                tf[static_cast<std::size_t>(s)] = std::max(t[static_cast<std::size_t>(s)][static_cast<std::size_t>(k)], rr) + lat;
+            }
+            for (const GroupPlan::UEntry& u : col.u) {
+                const int tu = u.isConst ? 0 : t[static_cast<std::size_t>(sk)][static_cast<std::size_t>(u.j)] + lat;
+                for (int s : col.lSlots) {
+                    int& d = t[static_cast<std::size_t>(s)][static_cast<std::size_t>(u.j)];
+                    d = std::max(d, std::max(tf[static_cast<std::size_t>(s)], tu)) + lat;
+                }
+            }
+        }
+        gp.depthElimination = 0;
+        for (int s = 0; s < S; ++s) for (int j = 0; j <= N; ++j) gp.depthElimination = std::max(gp.depthElimination, t[static_cast<std::size_t>(s)][static_cast<std::size_t>(j)]);
+        for (int j = N - 1; j >= 0; --j) {
+            const int sj = j / kGroupLanes;
+            const int tx = std::max(t[static_cast<std::size_t>(sj)][static_cast<std::size_t>(N)], tr[static_cast<std::size_t>(j)]) + lat + lat;
+            worst = std::max(worst, tx);
+            for (int s : gp.backSlots[static_cast<std::size_t>(j)]) {
+                int& d = t[static_cast<std::size_t>(s)][static_cast<std::size_t>(N)];
+                d = std::max(d, std::max(tx, t[static_cast<std::size_t>(s)][static_cast<std::size_t>(j)])) + lat;
+            }
+        }
+        gp.depthSolve = worst;
+    }
+
     gp.gCellPtr.assign(1, 0);
     for (const auto& c : cellCon) {
         gp.gCellCon.insert(gp.gCellCon.end(), c.begin(), c.end());

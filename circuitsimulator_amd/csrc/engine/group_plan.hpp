@@ -82,6 +82,9 @@ struct GroupPlan {
 
     // operation counts of one solve (wave-level instructions, 4 instances each)
     int nBcast = 0, nFma = 0, nMul = 0, nCmp = 0, nRecip = 0;
+    // critical path of one solve in cycles under a simple latency model (8 cycles per dependent VALU
+    // result, 40 for a Newton-refined reciprocal): after the elimination, and after back substitution
+    int depthElimination = 0, depthSolve = 0;
 };
 
 // false: the circuit does not fit this kernel (N > 48, no Newton terms to stage, ...)

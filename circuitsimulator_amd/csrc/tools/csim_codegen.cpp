@@ -99,8 +99,9 @@ static int selftestGroup(const csim_ir* ir, const csim::AssemblyPlan& ap, const 
                 if (e > worst) { worst = e; worstAlt = (int)alt; }
             }
         }
-        std::printf("group plan alt %zu: N=%d slots=%d classes=%zu staging rows=%zu  per solve (wave instructions): bcast=%d fma=%d mul=%d cmp=%d recip=%d\n",
-                    alt, gp.N, gp.S, gp.gClasses.size(), gp.stageRows.size(), gp.nBcast, gp.nFma, gp.nMul, gp.nCmp, gp.nRecip);
+        std::printf("group plan alt %zu: N=%d slots=%d classes=%zu staging rows=%zu  per solve (wave instructions): bcast=%d fma=%d mul=%d cmp=%d recip=%d; critical path %d cycles after elimination, %d after substitution\n",
+                    alt, gp.N, gp.S, gp.gClasses.size(), gp.stageRows.size(), gp.nBcast, gp.nFma, gp.nMul, gp.nCmp, gp.nRecip,
+                    gp.depthElimination, gp.depthSolve);
     }
     std::printf("group plan self test: worst relative difference to the dense elimination %.3g (alternative %d)\n", worst, worstAlt);
     return worst < 1e-9 ? 0 : 4;
