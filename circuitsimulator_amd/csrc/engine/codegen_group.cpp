@@ -130,11 +130,17 @@ __device__ __forceinline__ void grp_mos_eval(double p, double Vth, double K, dou
     const double Vov = Vgs - Vth;
     const bool on = (Vgs > Vth) && (Vds >= 0.0);
     const bool tri = Vds < Vov;
-    const double Ids0 = on ? (tri ? K * (Vov * Vds - 0.5 * Vds * Vds) : 0.5 * K * Vov * Vov) : 0.0;
-    const double gds0 = on ? (tri ? K * (Vov - Vds) : 0.0) : offGds;
-    const double gm0 = on ? (tri ? K * Vds : K * Vov) : 0.0;
-    double factor = 1.0 + lambda * Vds;
-    if (factor < 0.0) factor = 0.0;
+    // both regions are evaluated and one is selected (v_cndmask): 16 lanes of a group may be in different
+    // regions, and a branch would split the Newton loop's single basic block
+    const double idTri = K * (Vov * Vds - 0.5 * Vds * Vds), idSat = 0.5 * K * Vov * Vov;
+    const double gdsTri = K * (Vov - Vds);
+    const double gmTri = K * Vds, gmSat = K * Vov;
+    const double idOn = tri ? idTri : idSat, gdsOn = tri ? gdsTri : 0.0, gmOn = tri ? gmTri : gmSat;
+    const double Ids0 = on ? idOn : 0.0;
+    const double gds0 = on ? gdsOn : offGds;
+    const double gm0 = on ? gmOn : 0.0;
+    const double f1 = 1.0 + lambda * Vds;
+    const double factor = f1 < 0.0 ? 0.0 : f1;
     const double Ids = p * (Ids0 * factor);
     gd = gds0 * factor + Ids0 * lambda;
     gg = gm0 * factor;
@@ -161,7 +167,8 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
     const int nStage = static_cast<int>(gp.stageRows.size());
 
     // LDS carve-up per instance (doubles)
-    const int oXS = 0, oXP = oXS + NP + 1, oXR = oXP + NP + 1, oTT = oXR + NP, oST = oTT + ap.nTerms;
+    const int nT1 = ap.nTerms + 1;                              // + one dummy term (always 0) for padded table entries
+    const int oXS = 0, oXP = oXS + NP + 1, oTT = oXP + NP + 1, oTS = oTT + nT1, oPL = oTS + 2 * nT1, oST = oPL + ir.n_params;
     const int instDoubles = oST + (nStage + 1) * G;
     if (instDoubles * 8 * 4 > 64 * 1024) return std::string();  // keep 2+ waves per CU possible; larger circuits: no group kernel
 
@@ -187,6 +194,48 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
         }
         o << intArray("grp_mosElem", mosTab) << intArray("grp_mosDest", destTab);
     }
+    // per-step work, lane-parallel with per-lane descriptors loaded once per launch:
+    //  sources (round r: lane g evaluates source element grp_src[r*16+g]);
+    //  history terms out = -TT[gterm] * (XP[a] - XP[b]) (tanalisis.cpp:77,308,337-341), packed a | b<<8, gterm | out<<16;
+    //  right-hand side: per slot a padded list of signed per-step terms (index 2*term + negate into TS)
+    std::vector<int32_t> srcTab;
+    for (int e = 0; e < ir.n_elems; ++e) if (ir.kind[e] == CSIM_V || ir.kind[e] == CSIM_I) srcTab.push_back(e);
+    const int srcRounds = (static_cast<int>(srcTab.size()) + G - 1) / G;
+    srcTab.resize(static_cast<std::size_t>(std::max(1, srcRounds) * G), -1);
+    std::vector<int32_t> hA, hG;
+    {
+        const int dummy = ap.nTerms;
+        auto node = [&](int eq) { return eq >= 0 ? eq : NP; };
+        auto add = [&](int gterm, int a, int b, int out) { hA.push_back(node(a) | (node(b) << 8)); hG.push_back(gterm | (out << 16)); };
+        for (int e = 0; e < ir.n_elems; ++e) {
+            const int tb = ap.termBase[static_cast<std::size_t>(e)];
+            const int32_t* q = ir.eq + 4 * e;
+            if (ir.kind[e] == CSIM_C) add(tb + T_C_GC, q[0], q[1], tb + T_C_IH);
+            else if (ir.kind[e] == CSIM_L) { const int kb = ir.branch_eq[e]; add(tb + T_L_REQ, (kb >= 0 && kb < N) ? kb : -1, -1, tb + T_L_VH); }
+            else if (ir.kind[e] == CSIM_NMOS || ir.kind[e] == CSIM_PMOS) {
+                add(tb + T_M_GCH, q[1], q[2], tb + T_M_IHGS);
+                add(tb + T_M_GCH, q[1], q[0], tb + T_M_IHGD);
+                add(tb + T_M_GCF, q[2], q[3], tb + T_M_IHSB);
+                add(tb + T_M_GCF, q[0], q[3], tb + T_M_IHDB);
+            }
+        }
+        while (hA.size() % G) { hA.push_back(NP | (NP << 8)); hG.push_back(dummy | (dummy << 16)); }
+        if (ap.nTerms >= 65535 || NP >= 255) return std::string();
+    }
+    const int histRounds = static_cast<int>(hA.size()) / G;
+    std::vector<int> rhsMax(static_cast<std::size_t>(S), 0);
+    std::vector<int32_t> rhsIdx;
+    for (int s = 0; s < S; ++s) {
+        for (int lane = 0; lane < G; ++lane)
+            rhsMax[static_cast<std::size_t>(s)] = std::max(rhsMax[static_cast<std::size_t>(s)],
+                gp.iCellPtr[static_cast<std::size_t>(s * G + lane + 1)] - gp.iCellPtr[static_cast<std::size_t>(s * G + lane)]);
+        for (int t = 0; t < rhsMax[static_cast<std::size_t>(s)]; ++t)
+            for (int lane = 0; lane < G; ++lane) {
+                const int lo = gp.iCellPtr[static_cast<std::size_t>(s * G + lane)], hi = gp.iCellPtr[static_cast<std::size_t>(s * G + lane + 1)];
+                rhsIdx.push_back(lo + t < hi ? gp.iCellCon[static_cast<std::size_t>(lo + t)] : 2 * ap.nTerms);   // padding: + the dummy zero
+            }
+    }
+    o << intArray("grp_src", srcTab) << intArray("grp_hA", hA) << intArray("grp_hG", hG) << intArray("grp_rhs", rhsIdx);
 
     o << "\n// One DPP row of 16 lanes = one circuit instance, 4 instances per wavefront (group_plan.hpp).\n"
       << "// pivot schedule: " << (sch.str().empty() ? std::string("-") : sch.str()) << "\n"
@@ -206,16 +255,18 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
       << "    if (!__any(inb && done[bb] < nSteps)) return;\n"
       << "    double* const XS = lds + q * " << instDoubles << " + " << oXS << ";   // iterate; XS[" << NP << "] = 0 (ground)\n"
       << "    double* const XP = lds + q * " << instDoubles << " + " << oXP << ";   // state at the start of the step (history, checkpoint)\n"
-      << "    double* const XR = lds + q * " << instDoubles << " + " << oXR << ";   // raw Newton solution\n"
-      << "    double* const TT = lds + q * " << instDoubles << " + " << oTT << ";   // element terms (plan.hpp)\n"
+      << "    double* const TT = lds + q * " << instDoubles << " + " << oTT << ";   // element terms (plan.hpp); TT[" << ap.nTerms << "] = 0 (padding)\n"
+      << "    double* const TS = lds + q * " << instDoubles << " + " << oTS << ";   // per-step terms with sign: TS[2t] = +TT[t], TS[2t+1] = -TT[t]\n"
+      << "    double* const PL = lds + q * " << instDoubles << " + " << oPL << ";   // this instance's parameters\n"
       << "    double* const ST = lds + q * " << instDoubles << " + " << oST << ";   // MOSFET staging rows [row][16]; last row = dummy\n"
       << "    const unsigned long long rowBits = 0xFFFFull << (16 * q);\n"
       << "    auto P = [&](int slot) -> double { return params[(long long)slot * SB + bb]; };\n\n";
 
     // ---- launch setup: zero staging, constants, terms
     o << "    for (int i = g; i < " << (nStage + 1) * G << "; i += 16) ST[i] = 0.0;\n"
-      << "    for (int i = g; i < " << ap.nTerms << "; i += 16) TT[i] = 0.0;\n"
-      << "    for (int i = g; i < " << NP << "; i += 16) XR[i] = 0.0;\n"
+      << "    for (int i = g; i < " << nT1 << "; i += 16) TT[i] = 0.0;\n"
+      << "    for (int i = g; i < " << 2 * nT1 << "; i += 16) TS[i] = 0.0;\n"
+      << "    for (int i = g; i < " << ir.n_params << "; i += 16) PL[i] = P(i);\n"
       << "    if (g == 0) { XS[" << NP << "] = 0.0; XP[" << NP << "] = 0.0; }\n"
       << "    grp_sync();\n"
       << "    bool badL = false;\n"
@@ -261,6 +312,17 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
               << " + g) * 8 + " << kd << "] : " << nStage * G << " + g;\n";
     }
 
+    for (int r = 0; r < srcRounds; ++r)
+        o << "    const int se" << r << " = grp_src[" << r * G << " + g];       // source evaluated by this lane in round " << r << "\n";
+    for (int r = 0; r < histRounds; ++r)
+        o << "    const int hA" << r << " = grp_hA[" << r * G << " + g], hG" << r << " = grp_hG[" << r * G << " + g];\n";
+    {
+        int base = 0;
+        for (int s = 0; s < S; ++s)
+            for (int t = 0; t < rhsMax[static_cast<std::size_t>(s)]; ++t, ++base)
+                o << "    const int ri" << s << "_" << t << " = grp_rhs[" << base * G << " + g];\n";
+    }
+
     // ---- state
     o << "\n    // state: lane g keeps x[16 s + g]\n";
     for (int s = 0; s < S; ++s) {
@@ -285,32 +347,23 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
       << "        if (live) {";
     for (int s = 0; s < S; ++s) o << " XP[" << s * G << " + g] = xo" << s << ";";
     o << " }\n"
-      << "        grp_sync();\n"
-      << "        // per-step terms: sources and history currents (tanalisis.cpp:77,308,337-341; sim.hpp:160-162)\n"
-      << "        for (int e = g; e < " << ir.n_elems << "; e += 16) {\n"
-      << "            const int kind = grp_kind[e], sl = grp_slot[e], tb = grp_tbase[e];\n"
-      << "            const int* eq4 = grp_eq + 4 * e;\n"
-      << "            if (kind == " << CSIM_V << " || kind == " << CSIM_I << ") {\n"
-      << "                TT[tb + " << T_SRC_VAL << "] = grp_source_tran([&](int i) { return P(sl + i); }, grp_wave[e], grp_waveN[e], tNow, " << lit(K.pi) << ");\n"
-      << "            } else if (kind == " << CSIM_C << ") {\n"
-      << "                const double vPrev = XP[eq4[0] >= 0 ? eq4[0] : " << NP << "] - XP[eq4[1] >= 0 ? eq4[1] : " << NP << "];\n"
-      << "                TT[tb + " << T_C_IH << "] = -TT[tb + " << T_C_GC << "] * vPrev;\n"
-      << "            } else if (kind == " << CSIM_L << ") {\n"
-      << "                const int kb = grp_branch[e];\n"
-      << "                TT[tb + " << T_L_VH << "] = -TT[tb + " << T_L_REQ << "] * XP[(kb >= 0 && kb < " << N << ") ? kb : " << NP << "];\n"
-      << "            } else if (kind == " << CSIM_NMOS << " || kind == " << CSIM_PMOS << ") {\n"
-      << "                const double vD = XP[eq4[0] >= 0 ? eq4[0] : " << NP << "], vG = XP[eq4[1] >= 0 ? eq4[1] : " << NP << "];\n"
-      << "                const double vS = XP[eq4[2] >= 0 ? eq4[2] : " << NP << "], vB = XP[eq4[3] >= 0 ? eq4[3] : " << NP << "];\n"
-      << "                const double gh = TT[tb + " << T_M_GCH << "], gf = TT[tb + " << T_M_GCF << "];\n"
-      << "                TT[tb + " << T_M_IHGS << "] = -gh * (vG - vS);\n"
-      << "                TT[tb + " << T_M_IHGD << "] = -gh * (vG - vD);\n"
-      << "                TT[tb + " << T_M_IHSB << "] = -gf * (vS - vB);\n"
-      << "                TT[tb + " << T_M_IHDB << "] = -gf * (vD - vB);\n"
-      << "            }\n"
-      << "        }\n"
-      << "        grp_sync();\n";
-    for (int s = 0; s < S; ++s)
-        o << "        const double cb" << s << " = grp_gather(TT, grp_iPtr, grp_iCon, " << s * G << " + g);   // right-hand side without the MOSFET terms\n";
+      << "        // per-step terms: sources (sim.hpp:160-162) and history currents (tanalisis.cpp:77,308,337-341)\n";
+    for (int r = 0; r < srcRounds; ++r)
+        o << "        if (se" << r << " >= 0) {\n"
+          << "            const int sl = grp_slot[se" << r << "], tb = grp_tbase[se" << r << "];\n"
+          << "            const double v = grp_source_tran([&](int i) { return PL[sl + i]; }, grp_wave[se" << r << "], grp_waveN[se" << r << "], tNow, " << lit(K.pi) << ");\n"
+          << "            TS[2 * tb] = v; TS[2 * tb + 1] = -v;\n"
+          << "        }\n";
+    for (int r = 0; r < histRounds; ++r)
+        o << "        {\n"
+          << "            const double v = -TT[hG" << r << " & 0xFFFF] * (XP[hA" << r << " & 0xFF] - XP[hA" << r << " >> 8]);\n"
+          << "            TS[2 * (hG" << r << " >> 16)] = v; TS[2 * (hG" << r << " >> 16) + 1] = -v;\n"
+          << "        }\n";
+    o << "        // right-hand side without the MOSFET terms, per-step terms summed in the reference's stamping order\n";
+    for (int s = 0; s < S; ++s) {
+        o << "        double cb" << s << " = 0.0;\n";
+        for (int t = 0; t < rhsMax[static_cast<std::size_t>(s)]; ++t) o << "        cb" << s << " += TS[ri" << s << "_" << t << "];\n";
+    }
 
     const int slowIters = slowStepIters(K.tran_tol, K.tran_alpha, K.tran_max_iters);
     const std::string in = "            ";
@@ -325,13 +378,15 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
           << in << "    double gd, gg, gs, cst;\n"
           << in << "    grp_mos_eval(mp" << R << ", mvth" << R << ", mK" << R << ", mlam" << R << ", " << lit(K.mos_off_gds)
           << ", XS[mD" << R << "], XS[mG" << R << "], XS[mS" << R << "], gd, gg, gs, cst);\n"
-          << in << "    if (me" << R << " >= 0) {\n"
-          << in << "        ST[md" << R << "_0] = gd; ST[md" << R << "_1] = gg; ST[md" << R << "_2] = gs; ST[md" << R << "_3] = -cst;\n"
-          << in << "        ST[md" << R << "_4] = -gd; ST[md" << R << "_5] = -gg; ST[md" << R << "_6] = -gs; ST[md" << R << "_7] = cst;\n"
-          << in << "    }\n"
+          << in << "    // lanes without a MOSFET write the dummy row (their destinations all point there): no branch\n"
+          << in << "    ST[md" << R << "_0] = gd; ST[md" << R << "_1] = gg; ST[md" << R << "_2] = gs; ST[md" << R << "_3] = -cst;\n"
+          << in << "    ST[md" << R << "_4] = -gd; ST[md" << R << "_5] = -gg; ST[md" << R << "_6] = -gs; ST[md" << R << "_7] = cst;\n"
           << in << "}\n";
     }
-    o << in << "grp_sync();\n";
+    // No fence here or anywhere inside the Newton loop: the LDS executes one wave's instructions in issue
+    // order, and the compiler keeps a store and a later load of the same LDS array in program order (they
+    // may alias).  A __syncthreads() would add nothing but a scheduling barrier and a full lgkmcnt(0) wait
+    // (measured: 30 % of the wave's cycles in s_waitcnt with four of them per iteration).
 
     // ---- assembly: class registers
     o << in << "// assembly: (terms constant within the step) + (MOSFET terms from the staging rows, in stamping order)\n";
@@ -352,7 +407,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
     }
 
     // ---- elimination
-    o << in << "int bad = 0;   // column + 1 of a failed pivot check on this lane's rows\n";
+    o << in << "double worst = -1.0, tie = -1.0;   // pivot checks of this lane's rows (see the first column)\n";
     std::vector<std::string> rinv(static_cast<std::size_t>(N));
     for (int k = 0; k < N; ++k) {
         const GroupPlan::Column& col = gp.cols[static_cast<std::size_t>(k)];
@@ -360,7 +415,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
         const std::string ak = "a_" + std::to_string(sk) + "_" + std::to_string(k);
         o << in << "// column " << k << ": pivot row = lane " << lk << ", slot " << sk << "\n";
         if (col.zeroPivot || col.contradiction) {
-            o << in << "bad = " << (k + 1) << ";   // scheduled pivot is a structural zero / contradicts exact constants\n";
+            o << in << "worst = 1.0;   // scheduled pivot is a structural zero / contradicts exact constants\n";
             rinv[static_cast<std::size_t>(k)] = "0.0";
             continue;
         }
@@ -371,13 +426,16 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
         } else {
             o << in << "const double pb" << k << " = grp_bc<" << lk << ">(" << ak << ");\n";
             absP = "fabs(pb" + std::to_string(k) + ")";
-            o << in << "bad = (" << absP << " >= " << lit(K.lu_eps) << ") ? bad : " << (k + 1) << ";\n";
+            o << in << "worst = fmax(worst, " << lit(K.lu_eps) << " - " << absP << ");\n";
         }
         // Candidates (solver.hpp:48-56).  Every lane is compared: rows that are no candidates hold an exact
         // zero in column k (structural zero) or are finished rows of the slot being consumed, which the 0/1
         // factor mk removes.  |pivot| >= |a| must hold for all of them; rows that come BEFORE the scheduled
-        // row in the reference's scan must also differ from it (first maximum wins a tie).  Failures are
-        // recorded per lane as the column number + 1 (a select per test: no scalar masks to keep alive).
+        // row in the reference's scan must also differ from it (first maximum wins a tie).  Arithmetic
+        // form, two vector operations per test and nothing scalar: worst = max(|a| - |pivot|) must stay
+        // <= 0, and tie = the same maximum over the rows that must be strictly smaller must stay < 0.
+        // (fmax drops a NaN operand; a NaN anywhere in the solve makes the update norm non-finite, which
+        // is a violation too.)
         {
             std::vector<unsigned> strictOf(static_cast<std::size_t>(S), 0u), anyOf(static_cast<std::size_t>(S), 0u);
             for (const GroupPlan::Check& c : col.checks) {
@@ -386,13 +444,14 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
             }
             for (int s = 0; s < S; ++s) {
                 if (!anyOf[static_cast<std::size_t>(s)]) continue;
-                const std::string thr = "th" + std::to_string(k) + "_" + std::to_string(s);
-                o << in << "const double " << thr << " = fabs(a_" << s << "_" << k << ")" << (s == sk ? " * mk" + std::to_string(lk) : std::string()) << ";\n"
-                  << in << "bad = (" << absP << " >= " << thr << ") ? bad : " << (k + 1) << ";\n";
+                const std::string d = "dc" + std::to_string(k) + "_" + std::to_string(s);
+                o << in << "const double " << d << " = fabs(a_" << s << "_" << k << ")" << (s == sk ? " * mk" + std::to_string(lk) : std::string())
+                  << " - " << absP << ";\n"
+                  << in << "worst = fmax(worst, " << d << ");\n";
                 if (strictOf[static_cast<std::size_t>(s)]) {
                     char m[16];
                     std::snprintf(m, sizeof m, "0x%04x", strictOf[static_cast<std::size_t>(s)] & 0xFFFFu);
-                    o << in << "bad = (" << absP << " == " << thr << " && ((" << m << " >> g) & 1)) ? " << (k + 1) << " : bad;\n";
+                    o << in << "tie = fmax(tie, ((" << m << " >> g) & 1) ? " << d << " : -1.0);\n";
                 }
             }
         }
@@ -436,33 +495,32 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
 
     // ---- back substitution, column-wise (solver.hpp:116-128)
     o << in << "// back substitution: x_j is formed in lane j % 16, broadcast, and subtracted from the rows above\n";
+    for (int s = 0; s < S; ++s) o << in << "double xr" << s << " = 0.0;\n";
     for (int j = N - 1; j >= 0; --j) {
         const int sj = j / G, lj = j % G;
-        o << in << "const double xb" << j << " = grp_bc<" << lj << ">(a_" << sj << "_" << N << " * " << rinv[static_cast<std::size_t>(j)] << ");\n"
-          << in << "XR[" << j << "] = xb" << j << ";\n";
+        o << in << "const double xt" << j << " = a_" << sj << "_" << N << " * " << rinv[static_cast<std::size_t>(j)] << ";\n"
+          << in << "xr" << sj << " = (g == " << lj << ") ? xt" << j << " : xr" << sj << ";      // lane " << lj << " keeps its own solution entry\n"
+          << in << "const double xb" << j << " = grp_bc<" << lj << ">(xt" << j << ");\n";
         for (int s : gp.backSlots[static_cast<std::size_t>(j)])
             o << in << "a_" << s << "_" << N << " = a_" << s << "_" << N << " - a_" << s << "_" << j << " * xb" << j << ";\n";
     }
-    o << in << "grp_sync();\n";
 
     // ---- damped update, norm, convergence (tanalisis.cpp:360-376)
     o << in << "double ss = 0.0;\n";
     for (int s = 0; s < S; ++s)
-        o << in << "const double xn" << s << " = xo" << s << " + " << lit(K.tran_alpha) << " * (XR[" << s * G << " + g] - xo" << s << ");\n"
+        o << in << "const double xn" << s << " = xo" << s << " + " << lit(K.tran_alpha) << " * (xr" << s << " - xo" << s << ");\n"
           << in << "{ const double d = xn" << s << " - xo" << s << "; ss += d * d; }\n";
     o << in << "ss = grp_sum16(ss);\n"
       << in << "const double err = sqrt(ss);\n"
-      << in << "const bool pv = (__ballot(bad != 0) & rowBits) != 0ull;\n"
-      << in << "if (active) {\n"
-      << in << "    if (pv || !(ss < 1.0e300)) { viol = true; active = false; }\n"
-      << in << "    else {\n"
-      << in << "        ++it;\n";
-    for (int s = 0; s < S; ++s) o << in << "        xo" << s << " = xn" << s << "; XS[" << s * G << " + g] = xn" << s << ";\n";
-    o << in << "        if (err < " << lit(K.tran_tol) << ") active = false;\n"
-      << in << "        else if (iter >= " << (slowIters - 1) << ") { viol = true; active = false; }   // slow step: plan.hpp slowStepIters\n"
-      << in << "    }\n"
-      << in << "}\n"
-      << in << "grp_sync();\n"
+      << in << "const bool pv = (__ballot(worst > 0.0 || tie >= 0.0) & rowBits) != 0ull;\n"
+      << in << "// branch-free bookkeeping (everything here is uniform within a group of 16 lanes)\n"
+      << in << "const bool good = active && !pv && (ss < 1.0e300);      // the solve stands: take the damped update\n"
+      << in << "const bool conv = err < " << lit(K.tran_tol) << ";\n"
+      << in << "const bool slow = !conv && iter >= " << (slowIters - 1) << ";                 // slow step: plan.hpp slowStepIters\n"
+      << in << "viol = viol || (active && !good) || (good && slow);\n"
+      << in << "it += good ? 1 : 0;\n";
+    for (int s = 0; s < S; ++s) o << in << "xo" << s << " = good ? xn" << s << " : xo" << s << "; XS[" << s * G << " + g] = xo" << s << ";\n";
+    o << in << "active = good && !conv && !slow;\n"
       << "        }\n"      // NR loop
       << "        if (live && !viol) {\n"
       << "            itTotal += it;\n"
