@@ -136,11 +136,18 @@ def test_buffer_10k_steps_batch1_config(engines, torch_mod, anchors):
     assert rel_err(r["wave"][:, :, 0], o["rows"][:, 1:]).max() < TOL
 
 
-def test_dbmixer_mc_transient_vs_oracle(engines, torch_mod):
+@pytest.mark.parametrize("lanes", [1, 16])
+def test_dbmixer_mc_transient_vs_oracle(engines, torch_mod, lanes):
+    """Both generated transient kernels (one lane per instance; sixteen lanes per instance) against the oracle."""
     nl, eng = engines["dbmixer"]
     B, steps = 64, 1500
     params = eng.mc_params(12345, 0.05, 0, B)
-    r = _run_tran(torch_mod, eng, params, steps, nl.tstep, probes=nl.probes, stride=100, want_step_iters=True)
+    eng.set_option("lanes_per_instance", lanes)
+    try:
+        assert eng.lanes_for_batch(B) == lanes
+        r = _run_tran(torch_mod, eng, params, steps, nl.tstep, probes=nl.probes, stride=100, want_step_iters=True)
+    finally:
+        eng.set_option("lanes_per_instance", 0)
     ph = params.cpu().numpy()
     for b in (0, 1, 2, 3, B - 1):
         o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstep * steps, want_step_iters=True)
@@ -187,6 +194,66 @@ def test_dbmixer_full_run_monte_carlo_instances(engines, torch_mod):
         o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstop, want_rows=False)
         assert o["n_steps"] == 50000 and its[b] == o["iters"], (b, its[b], o["iters"])
         assert rel_err(xs[:, b], o["x_final"]).max() < TOL
+
+
+# --------------------------------------- sixteen lanes per instance (group kernel)
+
+def test_group_kernel_ragged_batches_chunks_and_probes(engines, torch_mod):
+    """The sixteen-lanes-per-instance kernel packs 4 instances per wavefront: batch sizes that do not
+    fill the last wave, launches cut into chunks, probe rows -- all must equal the lane-per-instance
+    kernel (same NR counts per step, states within 1e-9) and, for the first and last instance, the oracle."""
+    nl, eng = engines["dbmixer"]
+    assert "group16" in eng.sched_info["text"]
+    for B in (1, 3, 5, 67, 256):
+        params = eng.mc_params(777, 0.05, 0, B)
+        eng.set_option("lanes_per_instance", 1)
+        ref = _run_tran(torch_mod, eng, params, 240, nl.tstep, probes=[1, 2, 30], stride=40, want_step_iters=True)
+        eng.set_option("lanes_per_instance", 16)
+        try:
+            got = _run_tran(torch_mod, eng, params, 240, nl.tstep, probes=[1, 2, 30], stride=40, want_step_iters=True,
+                            chunks=[1, 99, 140])
+        finally:
+            eng.set_option("lanes_per_instance", 0)
+        assert np.array_equal(got["step_iters"], ref["step_iters"]), B
+        assert np.array_equal(got["status"], ref["status"]) and not (got["status"] & 0x27).any(), B
+        assert rel_err(got["x"].T, ref["x"].T).max() < TOL, B
+        assert rel_err(got["wave"].reshape(-1, B).T, ref["wave"].reshape(-1, B).T).max() < TOL, B
+        ph = params.cpu().numpy()
+        for b in {0, B - 1}:
+            o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstep * 240, want_step_iters=True)
+            assert np.array_equal(got["step_iters"][:, b], o["step_iters"]), (B, b)
+            assert rel_err(got["x"][:, b], o["x_final"]).max() < TOL, (B, b)
+
+
+def test_group_kernel_hands_over_what_its_one_schedule_does_not_cover(engines, torch_mod):
+    """The group kernel carries the FIRST pivot schedule only.  buffer.sp at its shipped step alternates
+    between seven: every other factorisation is a violation there and goes through the hybrid stepping
+    (general kernel, hand-back).  Results must not care."""
+    nl, eng = engines["buffer"]
+    B = 96
+    params = eng.mc_params(4, 0.05, 0, B)
+    eng.set_kernel("general")
+    slow = _run_tran(torch_mod, eng, params, 300, nl.tstep, want_step_iters=True)
+    eng.set_kernel("auto")
+    assert eng.lanes_for_batch(B) == 1            # several alternatives: auto stays on the lane-per-instance kernel
+    eng.set_option("lanes_per_instance", 16)
+    try:
+        fast = _run_tran(torch_mod, eng, params, 300, nl.tstep, want_step_iters=True, chunks=[150, 150])
+    finally:
+        eng.set_option("lanes_per_instance", 0)
+    assert ((fast["status"] & FALLBACK) != 0).any()
+    assert np.array_equal(fast["step_iters"], slow["step_iters"])
+    assert np.array_equal(fast["status"] & NOFB, slow["status"])
+    assert rel_err(fast["x"].T, slow["x"].T).max() < TOL
+    # at 3e-11 s the first schedule holds for every factorisation: the group kernel alone, no hand-over
+    eng.set_option("lanes_per_instance", 16)
+    try:
+        r = _run_tran(torch_mod, eng, params[:, :9].contiguous(), 1000, 3e-11)
+    finally:
+        eng.set_option("lanes_per_instance", 0)
+    assert not (r["status"] & 0x27).any()
+    o = _orc().tran(nl.ir_ptr, nl.n_unknowns, params.cpu().numpy(), 8, 3e-11, 3e-11 * 1000, want_rows=False)
+    assert r["iters"][8] == o["iters"] and rel_err(r["x"][:, 8], o["x_final"]).max() < TOL
 
 
 # --------------------------------------- scheduled (lane-per-instance) kernels
