@@ -5,6 +5,6 @@ damped Newton update, for a batch of independent circuit instances, behind
 the C-ABI declared in include/csim.h (libcsim.so, HIP kernels for gfx950).
 """
 from .capi import CsimError, lib  # noqa: F401
-from .engine import Engine, Netlist, lu_decompose_batch, lu_solve_batch  # noqa: F401
+from .engine import Engine, Netlist, gs_solve_batch, lu_decompose_batch, lu_solve_batch  # noqa: F401
 
-__all__ = ["Engine", "Netlist", "CsimError", "lu_solve_batch", "lu_decompose_batch", "lib"]
+__all__ = ["Engine", "Netlist", "CsimError", "lu_solve_batch", "lu_decompose_batch", "gs_solve_batch", "lib"]

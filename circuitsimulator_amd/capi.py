@@ -71,6 +71,9 @@ PROTOTYPES = {
     "csim_tran_num_steps": (_i64, [_dbl, _dbl]),
     "csim_lu_solve_batch": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "csim_lu_decompose_batch": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "csim_gs_solve_batch": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _i32, _dbl, _vp, _vp]),
+    "csim_dc_gs_batch_dev": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "csim_dc_gs_batch": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "csim_engine_jit_scheduled": (C.c_int, [_vp, _vp, _i32, _dbl, _i64]),
     "csim_engine_jit_with_schedules": (C.c_int, [_vp, _vp, _i32, _vp, _i32]),
     "csim_engine_set_option": (C.c_int, [_vp, _cp, _cp]),

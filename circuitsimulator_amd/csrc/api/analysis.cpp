@@ -120,6 +120,53 @@ Eigen::VectorXd dcSolveLU(const Circuit& ckt)
 
 Eigen::VectorXd dcSolve(const Circuit& ckt) { return dcSolveLU(ckt); }
 
+Eigen::VectorXd dcSolveGaussSeidel(const Circuit& ckt)
+{
+    const int N = ckt.numUnknowns();
+    if (N == 0) {                                           // dcanalysis.cpp:75-78, 170-173
+        std::cerr << "DC solve (GS): no unknowns.\n";
+        return Eigen::VectorXd::Zero(0);
+    }
+    csim::BatchEngine eng(ckt, 0);
+    std::vector<double> x(static_cast<std::size_t>(N), 0.0);
+    int32_t iters = 0;
+    uint32_t status = 0;
+    if (csim_dc_gs_batch(eng.handle(), nullptr, 1, x.data(), &iters, &status) != CSIM_OK)
+        throw std::runtime_error(std::string("csim_dc_gs_batch: ") + csim_last_error());
+    if (status & CSIM_ST_DC_NONFINITE) std::cerr << "WARNING: GS produced non-finite x at one or more Newton passes (gmin was raised)\n";
+    if (status & CSIM_ST_DC_NONCONV) std::cerr << "WARNING: Newton (GS) did not converge within the iteration cap at one or more ramp steps\n";
+    Eigen::VectorXd out(N);
+    for (int i = 0; i < N; ++i) out(i) = x[static_cast<std::size_t>(i)];
+    return out;
+}
+
+// host arithmetic, for callers of the reference's header only (dcanalysis.hpp): src/dcanalysis.cpp:268-307
+ConvStatus ConvController::update(const Eigen::VectorXd& x, const Eigen::VectorXd& xRaw, double prevErr, int iter,
+                                  double /*alphaCurrent*/, double gminCurrent, double rampScale, double tol) const
+{
+    ConvStatus st;
+    double alpha = 0.35 < alphaMin ? alphaMin : (0.35 > alphaMax ? alphaMax : 0.35);       // :274
+    const long n = x.size();
+    Eigen::VectorXd xNew(n);
+    double ss = 0.0;
+    for (long i = 0; i < n; ++i) xNew(i) = x(i) + alpha * (xRaw(i) - x(i));
+    for (long i = 0; i < n; ++i) { const double d = xNew(i) - x(i); ss += d * d; }
+    const double err = std::sqrt(ss);
+    const double gminBase = baseGmin(rampScale);
+    double gminNext = gminBase;
+    if (!(iter == 0 || !std::isfinite(prevErr))) {
+        if (err > prevErr * slowConvRatio) { alpha = std::fmax(alpha * 0.7, alphaMin); gminNext = std::fmin(gminCurrent * 2.0, gminAbsMax); }
+        else if (err < prevErr * fastConvRatio) { alpha = std::fmin(alpha * 1.1, alphaMax); gminNext = 0.5 * gminCurrent + 0.5 * gminBase; }
+        else gminNext = 0.7 * gminCurrent + 0.3 * gminBase;
+    }
+    st.xNext = xNew;
+    st.alphaNext = alpha;
+    st.gminNext = gminNext;
+    st.error = err;
+    st.converged = err < tol;
+    return st;
+}
+
 // ------------------------------------------------------------- tanalisis.hpp
 
 Eigen::VectorXd computeDcOperatingPoint(const Circuit& ckt) { return dcSolve(ckt); }
@@ -211,6 +258,29 @@ VectorXd solveLinearSystemLU(const MatrixXd& A, const VectorXd& b)
     if (flags & CSIM_ST_LU_TINY_PIVOT) std::cerr << "LU solve: decomposition failed.\n";
     for (int i = 0; i < n; ++i) x(i) = sol[static_cast<std::size_t>(i)];
     return x;
+}
+
+VectorXd solveLinearSystemGaussSeidel(const MatrixXd& A, const VectorXd& b, const VectorXd& x0, int maxIters, double tol)
+{
+    const int n = static_cast<int>(A.rows());
+    if (n == 0) return x0;                                                   // solver.hpp:146
+    if (A.cols() != n || b.size() != n) { std::cerr << "Gauss-Seidel: dimension mismatch.\n"; return VectorXd::Zero(n); }
+    std::vector<double> a(static_cast<std::size_t>(n) * n), rhs(static_cast<std::size_t>(n)), start(rhs.size(), 0.0), sol(rhs.size());
+    for (int i = 0; i < n; ++i) {
+        rhs[static_cast<std::size_t>(i)] = b(i);
+        if (x0.size() == n) start[static_cast<std::size_t>(i)] = x0(i);      // a wrong-sized x0 starts from zero (:154-157)
+        for (int j = 0; j < n; ++j) a[static_cast<std::size_t>(i) * n + j] = A(i, j);
+    }
+    if (csim_gs_solve_batch(0, n, 1, a.data(), rhs.data(), start.data(), maxIters, tol, sol.data(), nullptr) != CSIM_OK)
+        throw std::runtime_error(std::string("csim_gs_solve_batch: ") + csim_last_error());
+    VectorXd x(n);
+    for (int i = 0; i < n; ++i) x(i) = sol[static_cast<std::size_t>(i)];
+    return x;
+}
+
+VectorXd solveLinearSystemGaussSeidel(const MatrixXd& A, const VectorXd& b, int maxIters, double tol)
+{
+    return solveLinearSystemGaussSeidel(A, b, VectorXd::Zero(b.size()), maxIters, tol);       // solver.hpp:197-204
 }
 
 } // namespace Solver

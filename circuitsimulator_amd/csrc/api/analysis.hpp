@@ -45,6 +45,7 @@ public:
     int numUnknowns() const { return ir_.view()->n_unknowns; }
     int numParams() const { return ir_.view()->n_params; }
     const CircuitIR& ir() const { return ir_; }
+    csim_engine* handle() const { return eng_; }          // for the C-ABI entry points without a C++ wrapper
     const std::vector<double>& nominalParams() const { return ir_.nominal; }
     // Monte-Carlo table [B][P] (instance-major) for instances bFirst..bFirst+B-1
     std::vector<double> monteCarloParams(uint64_t seed, double sigma, int64_t bFirst, int B) const;

@@ -16,6 +16,10 @@ class Circuit;
 // Newton for circuits with MOSFETs).  Needs a HIP device.
 Eigen::VectorXd dcSolve(const Circuit& ckt);
 Eigen::VectorXd dcSolveLU(const Circuit& ckt);
+// the same with the Gauss-Seidel inner solver (reference include/dcanalysis.hpp:14,
+// src/dcanalysis.cpp:71-92,166-237): HIP kernel k_dc_gs.  Upstream nothing calls it; on circuits with
+// voltage sources every inner solve diverges and the zero vector comes back, here as there.
+Eigen::VectorXd dcSolveGaussSeidel(const Circuit& ckt);
 
 struct ConvStatus {
     Eigen::VectorXd xNext;
@@ -25,15 +29,17 @@ struct ConvStatus {
     bool converged;
 };
 
-// Constants of the reference's convergence controller (src/dcanalysis.cpp:264-265).
-// The update rule itself runs per instance on the device; the class is kept
-// for callers that query the gmin schedule.
+// The reference's convergence controller (src/dcanalysis.cpp:264-307).  The DC kernels run this rule
+// per instance on the device; the host class is kept, update() included, for callers of the
+// reference's header -- plain host arithmetic on the two vectors it is given, used by no analysis here.
 class ConvController {
     double alphaMin, alphaMax;
     double gminHighBase, gminLowBase, gminAbsMax;
     double fastConvRatio, slowConvRatio;
 public:
     ConvController();
+    ConvStatus update(const Eigen::VectorXd& x, const Eigen::VectorXd& xRaw, double prevErr, int iter,
+                      double alphaCurrent, double gminCurrent, double rampScale, double tol) const;
     double baseGmin(double rampScale) const;
     double alphaLow() const { return alphaMin; }
     double alphaHigh() const { return alphaMax; }

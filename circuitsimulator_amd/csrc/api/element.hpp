@@ -49,9 +49,22 @@ public:
     const std::string& getName() const { return name; }
     const std::vector<int>& getNodeIds() const { return nodeIds; }
 
-    // flatten this device for the engine (replaces Element::stamp,
-    // reference include/element.hpp:28-31)
+    // flatten this device for the engine: what the solve path uses instead of stamp()
     virtual csim::IrRecord describe(const Circuit& ckt) const = 0;
+
+    // The reference's stamping seam (include/element.hpp:28-31), kept for source compatibility:
+    // adds this device into a caller-owned HOST system at iterate x.  Host arithmetic for callers of
+    // the reference's headers only -- no analysis of this library calls it (api/stamp_host.cpp).
+    virtual void stamp(Eigen::MatrixXd& G, Eigen::VectorXd& I, const Circuit& ckt,
+                       const Eigen::VectorXd& x, const AnalysisContext& ctx) const;
+    // AC stamping is a stub upstream as well (include/element.hpp:33-38: the default does nothing,
+    // no analysis calls it); kept so that overriding code compiles.
+    virtual void stampAC(Eigen::MatrixXcd& /*Y*/, Eigen::VectorXcd& /*J*/, const Circuit& /*ckt*/,
+                         double /*omega*/) const {}
+
+protected:
+    // sources hand their SourceSpec to the host stamp
+    virtual const SourceSpec* sourceSpec() const { return nullptr; }
 };
 
 class Resistor : public Element {
@@ -71,6 +84,8 @@ public:
     const SourceSpec& getSpec() const { return spec; }
     const SourceSpec& setSpec() const { return spec; }   // (sic) name kept from the reference
     csim::IrRecord describe(const Circuit& ckt) const override;
+protected:
+    const SourceSpec* sourceSpec() const override { return &spec; }
 };
 
 class VoltageSource : public Element {
@@ -83,6 +98,8 @@ public:
     int  getBranchEqIndex() const { return branchEqIndex; }
     const SourceSpec& getSpec() const { return spec; }
     csim::IrRecord describe(const Circuit& ckt) const override;
+protected:
+    const SourceSpec* sourceSpec() const override { return &spec; }
 };
 
 // open circuit at DC, backward-Euler companion in transient

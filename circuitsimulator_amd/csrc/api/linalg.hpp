@@ -20,10 +20,13 @@
 namespace csim {
 using VectorXd = Eigen::VectorXd;
 using MatrixXd = Eigen::MatrixXd;
+using VectorXcd = Eigen::VectorXcd;
+using MatrixXcd = Eigen::MatrixXcd;
 }
 #else
 
 #include <cmath>
+#include <complex>
 #include <cstddef>
 #include <vector>
 
@@ -73,10 +76,36 @@ public:
     void setZero() { for (double& x : a_) x = 0.0; }
 };
 
+// complex containers: they appear in Element::stampAC's signature only (AC is a stub upstream)
+class VectorXcd {
+    std::vector<std::complex<double>> v_;
+public:
+    VectorXcd() = default;
+    explicit VectorXcd(long n) : v_(static_cast<std::size_t>(n < 0 ? 0 : n)) {}
+    static VectorXcd Zero(long n) { return VectorXcd(n); }
+    long size() const { return static_cast<long>(v_.size()); }
+    std::complex<double>&       operator()(long i)       { return v_[static_cast<std::size_t>(i)]; }
+    const std::complex<double>& operator()(long i) const { return v_[static_cast<std::size_t>(i)]; }
+};
+class MatrixXcd {
+    long r_ = 0, c_ = 0;
+    std::vector<std::complex<double>> a_;
+public:
+    MatrixXcd() = default;
+    MatrixXcd(long r, long c) : r_(r), c_(c), a_(static_cast<std::size_t>(r * c)) {}
+    static MatrixXcd Zero(long r, long c) { return MatrixXcd(r, c); }
+    long rows() const { return r_; }
+    long cols() const { return c_; }
+    std::complex<double>&       operator()(long i, long j)       { return a_[static_cast<std::size_t>(i * c_ + j)]; }
+    const std::complex<double>& operator()(long i, long j) const { return a_[static_cast<std::size_t>(i * c_ + j)]; }
+};
+
 } // namespace csim
 
 namespace Eigen {
 using VectorXd = ::csim::VectorXd;
 using MatrixXd = ::csim::MatrixXd;
+using VectorXcd = ::csim::VectorXcd;
+using MatrixXcd = ::csim::MatrixXcd;
 }
 #endif

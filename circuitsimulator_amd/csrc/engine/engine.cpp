@@ -661,6 +661,98 @@ int csim_tran_batch(csim_engine* eng, const double* params, int32_t B, double ts
     return CSIM_OK;
 }
 
+// ---- Gauss-Seidel variant (reference: include/solver.hpp:139-204, src/dcanalysis.cpp:71-92,166-237)
+
+int csim_dc_gs_batch_dev(csim_engine* eng, const double* d_params, int32_t B, double* d_x,
+                         int32_t* d_iters, uint32_t* d_status, void* stream)
+{
+    if (!eng || !d_params || !d_x || !d_iters || !d_status || B < 0) { setError("csim_dc_gs_batch_dev: bad argument"); return CSIM_ERR_ARG; }
+    if (B == 0) return CSIM_OK;
+    if (eng->big) { setError("the Gauss-Seidel DC kernel covers circuits of up to 63 unknowns"); return CSIM_ERR_UNSUPPORTED; }
+    HIPCHK(hipSetDevice(eng->device));
+    if (!eng->dGsRowPtr) {
+        const int N = eng->plan.N;
+        std::vector<int32_t> ptr(1, 0), col;
+        for (int i = 0; i < N; ++i) {
+            for (int j = 0; j < N; ++j)
+                if (j != i && eng->plan.patDc[(size_t)i * N + j]) col.push_back(j);
+            ptr.push_back((int32_t)col.size());
+        }
+        int rc = upload(eng, ptr, &eng->dGsRowPtr);
+        if (!rc) rc = upload(eng, col, &eng->dGsRowCol);
+        if (rc) return rc;
+    }
+    HIPCHK(csim::launchDcGs(eng->gpDc, eng->dGsRowPtr, eng->dGsRowCol, d_params, B, d_x, d_iters, d_status,
+                            static_cast<hipStream_t>(stream)));
+    return CSIM_OK;
+}
+
+int csim_dc_gs_batch(csim_engine* eng, const double* params, int32_t B, double* x_out,
+                     int32_t* nr_iters, uint32_t* status)
+{
+    if (!eng || B < 0) { setError("csim_dc_gs_batch: bad argument"); return CSIM_ERR_ARG; }
+    if (B == 0) return CSIM_OK;
+    HIPCHK(hipSetDevice(eng->device));
+    const int N = eng->plan.N;
+    DevBuf dParams, dX, dXt, dIt, dSt;
+    int rc = stageParams(eng, params, B, dParams);
+    if (rc) return rc;
+    HIPCHK(dX.alloc(sizeof(double) * (size_t)N * B));
+    HIPCHK(dXt.alloc(sizeof(double) * (size_t)N * B));
+    HIPCHK(dIt.alloc(sizeof(int32_t) * (size_t)B));
+    HIPCHK(dSt.alloc(sizeof(uint32_t) * (size_t)B));
+    rc = csim_dc_gs_batch_dev(eng, dParams.as<double>(), B, dX.as<double>(), dIt.as<int32_t>(), dSt.as<uint32_t>(), nullptr);
+    if (rc) return rc;
+    HIPCHK(csim::launchTranspose(dX.as<double>(), dXt.as<double>(), N, B, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    if (x_out)    HIPCHK(hipMemcpy(x_out, dXt.p, sizeof(double) * (size_t)N * B, hipMemcpyDeviceToHost));
+    if (nr_iters) HIPCHK(hipMemcpy(nr_iters, dIt.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost));
+    if (status)   HIPCHK(hipMemcpy(status, dSt.p, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost));
+    return CSIM_OK;
+}
+
+int csim_gs_solve_batch(int32_t device, int32_t n, int32_t B, const double* A, const double* b, const double* x0,
+                        int32_t max_iters, double tol, double* x, int32_t* sweeps)
+{
+    if (n < 0 || B < 0 || !x || (n > 0 && B > 0 && (!A || !b))) { setError("csim_gs_solve_batch: bad argument"); return CSIM_ERR_ARG; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {
+        setError("csim_gs_solve_batch: no usable HIP device (this library has no CPU path)");
+        return CSIM_ERR_NO_DEVICE;
+    }
+    if (n == 0 || B == 0) return CSIM_OK;                 // solver.hpp:146: empty system -> x0 unchanged (empty)
+    if (n > 4096) { setError("csim_gs_solve_batch covers n <= 4096"); return CSIM_ERR_UNSUPPORTED; }
+    HIPCHK(hipSetDevice(device));
+    // instance-major in, slot-major on the device (lanes = systems read consecutive doubles)
+    DevBuf dA, dAt, dB, dBt, dX0, dX0t, dX, dXt, dXo, dSw;
+    const size_t nn = (size_t)n * n;
+    HIPCHK(dA.alloc(sizeof(double) * nn * B));
+    HIPCHK(dAt.alloc(sizeof(double) * nn * B));
+    HIPCHK(dB.alloc(sizeof(double) * (size_t)n * B));
+    HIPCHK(dBt.alloc(sizeof(double) * (size_t)n * B));
+    HIPCHK(dX.alloc(sizeof(double) * (size_t)n * B));
+    HIPCHK(dXt.alloc(sizeof(double) * (size_t)n * B));
+    HIPCHK(dXo.alloc(sizeof(double) * (size_t)n * B));
+    HIPCHK(dSw.alloc(sizeof(int32_t) * (size_t)B));
+    HIPCHK(hipMemcpy(dA.p, A, sizeof(double) * nn * B, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dB.p, b, sizeof(double) * (size_t)n * B, hipMemcpyHostToDevice));
+    HIPCHK(csim::launchTranspose(dA.as<double>(), dAt.as<double>(), B, (int)nn, nullptr));      // [B][n*n] -> [n*n][B]
+    HIPCHK(csim::launchTranspose(dB.as<double>(), dBt.as<double>(), B, n, nullptr));
+    if (x0) {
+        HIPCHK(dX0.alloc(sizeof(double) * (size_t)n * B));
+        HIPCHK(dX0t.alloc(sizeof(double) * (size_t)n * B));
+        HIPCHK(hipMemcpy(dX0.p, x0, sizeof(double) * (size_t)n * B, hipMemcpyHostToDevice));
+        HIPCHK(csim::launchTranspose(dX0.as<double>(), dX0t.as<double>(), B, n, nullptr));
+    }
+    HIPCHK(csim::launchGsSolve(n, B, dAt.as<double>(), dBt.as<double>(), x0 ? dX0t.as<double>() : nullptr, max_iters, tol,
+                               dXt.as<double>(), dXo.as<double>(), dSw.as<int32_t>(), nullptr));
+    HIPCHK(csim::launchTranspose(dXt.as<double>(), dX.as<double>(), n, B, nullptr));            // [n][B] -> [B][n]
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(x, dX.p, sizeof(double) * (size_t)n * B, hipMemcpyDeviceToHost));
+    if (sweeps) HIPCHK(hipMemcpy(sweeps, dSw.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost));
+    return CSIM_OK;
+}
+
 int csim_lu_solve_batch(int32_t device, int32_t n, int32_t B, const double* A, const double* b,
                         double* x, uint32_t* flags)
 {

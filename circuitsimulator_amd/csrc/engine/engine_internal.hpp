@@ -65,6 +65,9 @@ struct csim_engine {
     double* dBigScratch = nullptr;
     int bigScratchCap = 0;                 // instances
 
+    // Gauss-Seidel DC: off-diagonal structure of the DC system per row (uploaded on first use)
+    const int32_t *dGsRowPtr = nullptr, *dGsRowCol = nullptr;
+
     // probe list of the most recent transient call
     int32_t* dProbe = nullptr;
     std::vector<int32_t> probeCache;

@@ -42,6 +42,13 @@ hipError_t launchTranBig(const GenPlan& pl, const double* dParams, int B, double
                          const uint8_t* dOnly, double* dScratch, const int32_t* dSlotOf, hipStream_t stream,
                          int32_t* dPivLog = nullptr, int pivInstance = -1, int32_t* dDone = nullptr, int maxSteps = 0);
 
+// Gauss-Seidel solver and the DC operating point built on it (kernels_gs.hip)
+hipError_t launchGsSolve(int n, int B, const double* dAt /*[n*n][B]*/, const double* dRhs /*[n][B]*/,
+                         const double* dX0 /*[n][B] or null*/, int maxIters, double tol, double* dX /*[n][B]*/,
+                         double* dXold /*[n][B] scratch*/, int32_t* dSweeps, hipStream_t stream);
+hipError_t launchDcGs(const GenPlan& pl, const int32_t* dRowPtr, const int32_t* dRowCol, const double* dParams, int B,
+                      double* dX, int32_t* dIters, uint32_t* dStatus, hipStream_t stream);
+
 // Monte-Carlo parameter table (mc.hip)
 hipError_t launchMcParams(int P, int B, long long bFirst, uint64_t seed, double sigma,
                           const int32_t* dKind, const double* dNominal, const double* dMu,

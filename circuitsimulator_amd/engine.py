@@ -195,6 +195,17 @@ class Engine:
                                                 st.data_ptr(), self._stream()))
         return x, it, st
 
+    def dc_gs(self, params):
+        """dcSolveGaussSeidel for a batch: params device [P][B] -> (x [N][B], iters, status)"""
+        torch = _torch()
+        B = params.shape[1]
+        x = torch.empty((self.N, B), dtype=torch.float64, device=self._dev())
+        it = torch.zeros(B, dtype=torch.int32, device=self._dev())
+        st = torch.zeros(B, dtype=torch.int32, device=self._dev())
+        capi.check(capi.lib().csim_dc_gs_batch_dev(self._h, params.data_ptr(), B, x.data_ptr(), it.data_ptr(),
+                                                   st.data_ptr(), self._stream()))
+        return x, it, st
+
     def dc_sweep(self, i=0):
         """Execute .DC card i of the netlist as one batch: -> (values, x [N][n], iters, status)."""
         values, table = self.netlist.dc_sweep_table(i)
@@ -342,6 +353,20 @@ def lu_solve_batch(A, b, device=0):
     capi.check(capi.lib().csim_lu_solve_batch(device, n, B, A.ctypes.data, b.ctypes.data, x.ctypes.data,
                                               flags.ctypes.data))
     return x, flags
+
+
+def gs_solve_batch(A, b, x0=None, max_iters=1000, tol=1e-10, device=0):
+    """Batched Solver::solveLinearSystemGaussSeidel on the GPU.  A [B][n][n], b/x0 [B][n] -> (x [B][n], sweeps [B])."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    B, n = b.shape
+    x0a = np.ascontiguousarray(x0, dtype=np.float64) if x0 is not None else None
+    x = np.zeros((B, n))
+    sweeps = np.zeros(B, dtype=np.int32)
+    capi.check(capi.lib().csim_gs_solve_batch(device, n, B, A.ctypes.data, b.ctypes.data,
+                                              x0a.ctypes.data if x0a is not None else None, int(max_iters), float(tol),
+                                              x.ctypes.data, sweeps.ctypes.data))
+    return x, sweeps
 
 
 def lu_decompose_batch(A, device=0):

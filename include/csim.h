@@ -193,6 +193,24 @@ int64_t csim_tran_num_steps(double tstep, double tstop);
 int  csim_lu_solve_batch(int32_t device, int32_t n, int32_t B, const double* A,
                          const double* b, double* x, uint32_t* flags);
 
+/* ---- Gauss-Seidel variant of the reference (never reached from its main(), kept as public API) ----
+ * Batched Solver::solveLinearSystemGaussSeidel (include/solver.hpp:139-204): sweeps in row order with the
+ * newest values, a diagonal below 1e-12 replaced by +-1e-12, stop when ||x - x_prev|| < tol or after
+ * max_iters sweeps; whatever the sweeps left is returned (it may be non-finite).  A [B][n][n] row-major,
+ * b / x0 / x [B][n] host pointers; x0 NULL = start from zero (the two-argument overload); sweeps [B]
+ * optional = sweeps performed.  One lane per system, same operation order as the reference.            */
+int  csim_gs_solve_batch(int32_t device, int32_t n, int32_t B, const double* A, const double* b,
+                         const double* x0, int32_t max_iters, double tol, double* x, int32_t* sweeps);
+/* dcSolveGaussSeidel (src/dcanalysis.cpp:71-92,166-237,254-258) for B instances: linear circuits one
+ * Gauss-Seidel solve (2000 sweeps, 1e-10), circuits with MOSFETs the source ramp with 60 (last step 120)
+ * Newton passes per step, inner solve warm-started from x, ConvController update.  A pass whose inner
+ * solve turns non-finite raises gmin x10 and is dropped (CSIM_ST_DC_NONFINITE), exactly as upstream; on
+ * circuits with voltage sources (zero diagonal entries) that is every pass and x stays 0.  N <= 63.   */
+int  csim_dc_gs_batch_dev(csim_engine* eng, const double* d_params /*[P][B]*/, int32_t B,
+                          double* d_x /*[N][B]*/, int32_t* d_iters, uint32_t* d_status, void* stream);
+int  csim_dc_gs_batch(csim_engine* eng, const double* params /*[B][P] or NULL*/, int32_t B,
+                      double* x_out /*[B][N]*/, int32_t* nr_iters, uint32_t* status);
+
 /* Runtime specialisation for a netlist without a prebuilt libcsim_sched_<topology>.so:
  * records the pivot schedule of instance 0 of d_params with the general kernel
  * (plan_steps transient steps), generates the lane-per-instance kernel, compiles it

@@ -37,6 +37,10 @@ def lib():
         L.oracle_stamp_tran.argtypes = [vp, vp, i64, vp, vp, dbl, dbl, vp, vp]
         L.oracle_dc.restype = C.c_int
         L.oracle_dc.argtypes = [vp, vp, i64, vp, vp, vp]
+        L.oracle_solve_gs.restype = C.c_int
+        L.oracle_solve_gs.argtypes = [C.c_int, vp, vp, vp, C.c_int, dbl, vp]
+        L.oracle_dc_gs.restype = C.c_int
+        L.oracle_dc_gs.argtypes = [vp, vp, i64, vp, vp, vp]
         L.oracle_tran.restype = i64
         L.oracle_tran.argtypes = [vp, vp, i64, dbl, dbl, dbl, vp, vp, i64, vp, vp, vp, vp, vp]
         L.oracle_tran_num_steps.restype = i64
@@ -107,6 +111,29 @@ def dc(ir, N, params, b=0):
     rc = lib().oracle_dc(ir, ptr, stride, x.ctypes.data, C.byref(it), C.byref(st))
     if rc != 0:
         raise RuntimeError("oracle_dc failed: %d" % rc)
+    return x, it.value, st.value
+
+
+def solve_gs(A, b, x0=None, max_iters=1000, tol=1e-10):
+    """Solver::solveLinearSystemGaussSeidel -> (x, sweeps)"""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x0a = np.ascontiguousarray(x0, dtype=np.float64) if x0 is not None else None
+    x = np.zeros(b.shape[0])
+    sweeps = lib().oracle_solve_gs(b.shape[0], A.ctypes.data, b.ctypes.data,
+                                   x0a.ctypes.data if x0a is not None else None, max_iters, tol, x.ctypes.data)
+    return x, sweeps
+
+
+def dc_gs(ir, N, params, b=0):
+    """dcSolveGaussSeidel -> (x[N], iters, status)"""
+    keep, ptr, stride = _col(params, b)
+    x = np.zeros(N)
+    it = C.c_int32()
+    st = C.c_uint32()
+    rc = lib().oracle_dc_gs(ir, ptr, stride, x.ctypes.data, C.byref(it), C.byref(st))
+    if rc != 0:
+        raise RuntimeError("oracle_dc_gs failed: %d" % rc)
     return x, it.value, st.value
 
 

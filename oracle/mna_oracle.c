@@ -536,6 +536,113 @@ int oracle_dc(const csim_ir* ir, const double* params, int64_t pstride,
     return 0;
 }
 
+/* ------------------------------------------------------------------ *
+ * Solver::solveLinearSystemGaussSeidel    include/solver.hpp:139-204
+ * x0 == NULL: start from the zero vector (the two-argument overload, :197-204).
+ * Returns the number of sweeps performed.
+ * ------------------------------------------------------------------ */
+int oracle_solve_gs(int n, const double* A, const double* b, const double* x0, int max_iters, double tol,
+                    double* x)
+{
+    if (n <= 0) return 0;                                    /* :146 */
+    for (int i = 0; i < n; ++i) x[i] = x0 ? x0[i] : 0.0;     /* :145, :154-157 */
+    double* xOld = (double*)malloc(sizeof(double) * (size_t)n);
+    const double diagEps = 1e-12;                            /* :160 */
+    int sweeps = 0;
+    for (int iter = 0; iter < max_iters; ++iter) {           /* :162 */
+        ++sweeps;
+        for (int i = 0; i < n; ++i) xOld[i] = x[i];          /* :163 */
+        for (int i = 0; i < n; ++i) {
+            double diag = A[i * n + i];                      /* :166 */
+            if (fabs(diag) < diagEps) {                      /* :169-173: keep the sign, default positive */
+                double sign = (diag >= 0.0 ? 1.0 : -1.0);
+                diag = sign * diagEps;
+            }
+            double sum = b[i];                               /* :175 */
+            for (int j = 0; j < i; ++j) sum -= A[i * n + j] * x[j];          /* :178-180 newest values */
+            for (int j = i + 1; j < n; ++j) sum -= A[i * n + j] * xOld[j];   /* :181-183 previous sweep */
+            x[i] = sum / diag;                               /* :185 */
+        }
+        double ss = 0.0;                                     /* :188 (x - xOld).norm(), summed in index order */
+        for (int i = 0; i < n; ++i) { double d = x[i] - xOld[i]; ss += d * d; }
+        if (sqrt(ss) < tol) break;                           /* :189-192 */
+    }
+    free(xOld);
+    return sweeps;
+}
+
+/* ------------------------------------------------------------------ *
+ * dcSolveGaussSeidel   src/dcanalysis.cpp:254-258 (dispatch), :71-92 (linear: one
+ * Gauss-Seidel solve of the system stamped at x = 0, scale 1, no gmin, 2000 sweeps,
+ * tol 1e-10), :166-237 (Newton ramp: 10 steps, 60 passes per step and 120 in the last,
+ * inner solve warm-started from x, ConvController::update).
+ * iters = passes through the Newton loop body (1 for the linear path).
+ * ------------------------------------------------------------------ */
+int oracle_dc_gs(const csim_ir* ir, const double* params, int64_t pstride,
+                 double* x, int32_t* iters, uint32_t* status)
+{
+    const int N = ir->n_unknowns;
+    const csim_consts* k = &ir->k;
+    int32_t it_total = 0;
+    uint32_t st = 0;
+    if (iters) *iters = 0;
+    if (status) *status = 0;
+    if (N <= 0) return -1;
+    const int gsSweeps = 2000;                               /* :88, :198 */
+    const double gsTol = 1e-10;
+    const int maxNewton = 60;                                /* :176 */
+    const double tol = 1e-9;                                 /* :177 */
+
+    double* G = (double*)malloc(sizeof(double) * (size_t)N * (size_t)N);
+    double* I = (double*)malloc(sizeof(double) * (size_t)N);
+    double* xRaw = (double*)malloc(sizeof(double) * (size_t)N);
+    double* xNew = (double*)malloc(sizeof(double) * (size_t)N);
+    for (int i = 0; i < N; ++i) x[i] = 0.0;
+
+    if (!ir->has_nonlinear) {
+        oracle_stamp_dc(ir, params, pstride, x, 1.0, -1.0, G, I);            /* :81-86 */
+        oracle_solve_gs(N, G, I, NULL, gsSweeps, gsTol, xRaw);               /* :89 */
+        for (int i = 0; i < N; ++i) x[i] = xRaw[i];
+        it_total = 1;
+    } else {
+        for (int step = 1; step <= k->dc_ramp_steps; ++step) {               /* :183 */
+            double scale = (double)step / k->dc_ramp_steps;
+            double gmin = base_gmin(k, scale);                               /* :186 */
+            double prevErr = INFINITY;
+            int maxIterThisStep = maxNewton;
+            if (step == k->dc_ramp_steps) maxIterThisStep = maxNewton * 2;   /* :189-191 */
+            for (int iter = 0; iter < maxIterThisStep; ++iter) {
+                oracle_stamp_dc(ir, params, pstride, x, scale, gmin, G, I);  /* :193-203 */
+                oracle_solve_gs(N, G, I, x, gsSweeps, gsTol, xRaw);          /* :206-207 warm start */
+                ++it_total;
+                if (!all_finite(xRaw, N)) {                                  /* :209-215 */
+                    double g10 = gmin * 10.0;
+                    gmin = g10 < 1e-2 ? g10 : 1e-2;
+                    st |= CSIM_ST_DC_NONFINITE;
+                    continue;
+                }
+                double alpha = clampd(k->dc_alpha, k->dc_alpha_min, k->dc_alpha_max);   /* update() ignores alphaCurrent, :274 */
+                double err = damped_update(N, alpha, x, xRaw, xNew);
+                double gminBase = base_gmin(k, scale);
+                double gminNext = gminBase;
+                if (iter == 0 || !isfinite(prevErr)) gminNext = gminBase;
+                else if (err > prevErr * k->slow_ratio) { double g2 = gmin * 2.0; gminNext = g2 < k->gmin_abs_max ? g2 : k->gmin_abs_max; }
+                else if (err < prevErr * k->fast_ratio) gminNext = 0.5 * gmin + 0.5 * gminBase;
+                else gminNext = 0.7 * gmin + 0.3 * gminBase;
+                for (int i = 0; i < N; ++i) x[i] = xNew[i];                  /* :220 */
+                gmin = gminNext;
+                prevErr = err;
+                if (err < tol) break;                                        /* :225-227 */
+                if (iter == maxNewton - 1) st |= CSIM_ST_DC_NONCONV;         /* :228-233: warns at pass 60 also in the last step */
+            }
+        }
+    }
+    free(G); free(I); free(xRaw); free(xNew);
+    if (iters) *iters = it_total;
+    if (status) *status = st;
+    return 0;
+}
+
 int64_t oracle_tran_num_steps(double tstep, double tstop)
 {
     if (!(tstep > 0.0) || !(tstop > 0.0)) return -1;        /* rejected at tanalisis.cpp:94-97 */

@@ -61,6 +61,16 @@ void oracle_stamp_tran(const csim_ir* ir, const double* params, int64_t pstride,
 int oracle_dc(const csim_ir* ir, const double* params, int64_t pstride,
               double* x, int32_t* iters, uint32_t* status);
 
+/* include/solver.hpp:139-204 (Gauss-Seidel with warm start x0, or from zero when x0 == NULL;
+ * a diagonal below 1e-12 is replaced by +-1e-12).  Returns the number of sweeps. */
+int oracle_solve_gs(int n, const double* A, const double* b, const double* x0, int max_iters, double tol,
+                    double* x);
+
+/* dcSolveGaussSeidel, src/dcanalysis.cpp:71-92,166-237,254-258: the DC operating point with the
+ * Gauss-Seidel inner solver (unreachable from the reference's main(), kept as its public API). */
+int oracle_dc_gs(const csim_ir* ir, const double* params, int64_t pstride,
+                 double* x, int32_t* iters, uint32_t* status);
+
 /* src/tanalisis.cpp:83-424.  If x0 != NULL it is used as the t=0 state in
  * place of the internally computed operating point (tanalisis.cpp:112).
  * rows: optional [max_rows][1+N] table receiving every written row
