@@ -8,9 +8,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <sstream>
 
 namespace csim {
+
+// codegen_linear.cpp
+void emitTranSourceValue(std::ostream& src, const std::string& i2, const csim_ir& ir, int e,
+                         const std::function<std::string(int)>& P, const std::string& target);
 
 // ------------------------------------------------------------ schedule utils
 
@@ -540,56 +545,8 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
                         src << i2 << sname(tb) << " = (" << pRef[static_cast<std::size_t>(s)] << " + " << pRef[static_cast<std::size_t>(s + 1)] << ") * scale;\n";
                     else
                         src << i2 << sname(tb) << " = " << pRef[static_cast<std::size_t>(s)] << " * scale;\n";
-                } else if (ir.wave[e] == CSIM_WAVE_SIN) {
-                    src << i2 << "if (tNow < " << pRef[static_cast<std::size_t>(s + 4)] << ") " << sname(tb) << " = " << pRef[static_cast<std::size_t>(s)] << " + " << pRef[static_cast<std::size_t>(s + 1)] << ";\n"
-                        << i2 << "else " << sname(tb) << " = " << pRef[static_cast<std::size_t>(s)] << " + (" << pRef[static_cast<std::size_t>(s + 1)] << " + " << pRef[static_cast<std::size_t>(s + 2)]
-                        << " * sin((2.0 * " << lit(K.pi) << " * " << pRef[static_cast<std::size_t>(s + 3)] << ") * (tNow - " << pRef[static_cast<std::size_t>(s + 4)] << ") + "
-                        << pRef[static_cast<std::size_t>(s + 5)] << "));\n";
-                } else if (ir.wave[e] == CSIM_WAVE_PULSE) {
-                    // TranWaveform::eval PULSE (reference include/sim.hpp:80-115)
-                    auto P = [&](int o) { return pRef[static_cast<std::size_t>(s + o)]; };
-                    src << i2 << "{\n"
-                        << i2 << "    const double v1 = " << P(1) << ", v2 = " << P(2) << ", td = " << P(3) << ", tr = " << P(4)
-                        << ", tf = " << P(5) << ", ton = " << P(6) << ", per = " << P(7) << ";\n"
-                        << i2 << "    double w;\n"
-                        << i2 << "    if (per <= 0.0) {\n"
-                        << i2 << "        const double tau = tNow - td;\n"
-                        << i2 << "        if (tau <= 0.0) w = v1;\n"
-                        << i2 << "        else if (tau < tr) w = v1 + clamp01_cg(tau / tr) * (v2 - v1);\n"
-                        << i2 << "        else if (tau < tr + ton) w = v2;\n"
-                        << i2 << "        else w = v2 + clamp01_cg((tau - (tr + ton)) / tf) * (v1 - v2);\n"
-                        << i2 << "    } else if (tNow < td) {\n"
-                        << i2 << "        w = v1;\n"
-                        << i2 << "    } else {\n"
-                        << i2 << "        double tau = fmod(tNow - td, per);\n"
-                        << i2 << "        if (tau < 0.0) tau += per;\n"
-                        << i2 << "        if (tau < tr) w = v1 + (v2 - v1) * clamp01_cg(tau / tr);\n"
-                        << i2 << "        else if (tau < tr + ton) w = v2;\n"
-                        << i2 << "        else if (tau < tr + ton + tf) w = v2 + (v1 - v2) * clamp01_cg((tau - (tr + ton)) / tf);\n"
-                        << i2 << "        else w = v1;\n"
-                        << i2 << "    }\n"
-                        << i2 << "    " << sname(tb) << " = " << P(0) << " + w;\n"
-                        << i2 << "}\n";
-                } else if (ir.wave[e] == CSIM_WAVE_PWL) {
-                    // TranWaveform::eval PWL (reference include/sim.hpp:124-138), unrolled over the points
-                    const int n = ir.wave_n[e];
-                    auto PT = [&](int i) { return pRef[static_cast<std::size_t>(s + 1 + i)]; };
-                    auto PV = [&](int i) { return pRef[static_cast<std::size_t>(s + 1 + n + i)]; };
-                    src << i2 << "{\n" << i2 << "    double w;\n";
-                    if (n <= 0) {
-                        src << i2 << "    w = 0.0;\n";
-                    } else {
-                        src << i2 << "    if (tNow <= " << PT(0) << ") w = " << PV(0) << ";\n"
-                            << i2 << "    else if (tNow >= " << PT(n - 1) << ") w = " << PV(n - 1) << ";\n";
-                        for (int i = 0; i + 1 < n; ++i)
-                            src << i2 << "    else if (tNow > " << PT(i) << " && tNow <= " << PT(i + 1) << ") { const double ta = " << PT(i)
-                                << ", tb = " << PT(i + 1) << ", va = " << PV(i) << ", vb = " << PV(i + 1)
-                                << "; w = va + (vb - va) * ((tNow - ta) / (tb - ta)); }\n";
-                        src << i2 << "    else w = " << PV(n - 1) << ";\n";
-                    }
-                    src << i2 << "    " << sname(tb) << " = " << pRef[static_cast<std::size_t>(s)] << " + w;\n" << i2 << "}\n";
                 } else {
-                    src << i2 << sname(tb) << " = " << pRef[static_cast<std::size_t>(s)] << " + 0.0;\n";
+                    emitTranSourceValue(src, i2, ir, e, [&](int o) { return pRef[static_cast<std::size_t>(s + o)]; }, sname(tb));
                 }
                 break;
             case CSIM_C:
@@ -1002,6 +959,14 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "    r = fma(fma(-a, r, 1.0), r, r);\n"
         << "    return r;\n}\n\n";
 
+    // linear circuits: factor once per launch, substitute once per step (codegen_linear.cpp).  It replaces
+    // the per-iteration kernels below for such circuits (they would re-factor in every Newton pass, and for
+    // N = 257 cost minutes of compile time)
+    int linWork = 0, linLanes = 0;
+    const std::string linSrc = emitLinearKernel(ir, ap, set.alts[0], &linWork, &linLanes);
+    const bool haveLinear = !linSrc.empty();
+    src << linSrc;
+
     const int leanBudget = 80 - N;
     // a variant is emitted only if its LDS image fits one CU (163 840 B)
     auto emitVariant = [&](const VariantOptions& opt, CodegenStats* st) {
@@ -1018,11 +983,11 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     // lean: 40 KB of LDS per wave (4 waves per CU): x, then finished U rows up to the budget;
     // for N > 80 the iterate alone exceeds that and the kernel runs fewer waves per CU
     CodegenStats leanStats;
-    const int ldsLean = emitVariant({"csim_tran_sched_kernel", false, false, leanBudget > 0 ? leanBudget : 0}, &leanStats);
+    const int ldsLean = haveLinear ? 0 : emitVariant({"csim_tran_sched_kernel", false, false, leanBudget > 0 ? leanBudget : 0}, &leanStats);
     if (statsOut) *statsOut = leanStats;
     if (ldsLean < 0) return std::string();          // the iterate does not fit LDS: no scheduled kernel
     // rich: same residency, every finished U row parked (more LDS per wave: fewer waves per CU)
-    const int ldsRich = emitVariant({"csim_tran_sched_kernel_rich", false, false, -1}, nullptr);
+    const int ldsRich = haveLinear ? -1 : emitVariant({"csim_tran_sched_kernel_rich", false, false, -1}, nullptr);
     const bool haveRich = ldsRich >= 0;
     const std::vector<int>& sweep = gopt.sweep;      // tuning aid (csim_codegen --sweep): extra kernels
     {
@@ -1072,6 +1037,9 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         src << " group16_wave_ops_per_solve: bcast=" << groupPlan.nBcast << " fma=" << groupPlan.nFma << " mul=" << groupPlan.nMul
             << " cmp=" << groupPlan.nCmp << " recip=" << groupPlan.nRecip;
     src << "\"; }\n"
+        << "// doubles per instance of the work area csim_sched_launch needs (0: none): the linear-circuit kernel parks\n"
+        << "// its factors there\n"
+        << "extern \"C\" int csim_sched_work_doubles(void) { return " << (haveLinear ? linWork : 0) << "; }\n"
         << "// 16 when this library also carries csim_tran_group_kernel (sixteen lanes per instance, first schedule only)\n"
         << "extern \"C\" int csim_sched_group_lanes(void) { return " << (haveGroup ? 16 : 0) << "; }\n";
     src << ""
@@ -1104,11 +1072,18 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "extern \"C\" int csim_sched_launch(const double* params, int B, double dt, long long stepFirst, long long nSteps,\n"
         << "                                 const int* probeEq, int nProbe, int outStride, double* wave, double* xio,\n"
         << "                                 long long* iters, unsigned* status, int* stepIters, unsigned char* fallback,\n"
-        << "                                 int* done, int* violFlag, void* stream, int variant)\n{\n"
+        << "                                 int* done, int* violFlag, double* work, void* stream, int variant)\n{\n"
         << "    if (B <= 0) return 0;\n"
         << "    const unsigned waves = (unsigned)((B + 63) / 64);\n"
         << "    const bool rich = " << (haveRich ? "(variant == 2)" : "false") << ";\n"
         ;
+    src << "    (void)work;\n";
+    if (haveLinear)
+        src << "    if (work) {   // linear circuit: factor once per launch, substitute once per step\n"
+            << "        hipLaunchKernelGGL(csim_tran_linear_kernel, dim3((unsigned)((B + " << linLanes - 1 << ") / " << linLanes << ")), dim3(" << linLanes << "), 0, (hipStream_t)stream,\n"
+            << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
+            << "                           stepIters, fallback, done, violFlag, work);\n"
+            << "        return (int)hipGetLastError();\n    }\n";
     if (haveGroup)
         src << "    if (variant == 16) {\n"
             << "        hipLaunchKernelGGL(csim_tran_group_kernel, dim3((unsigned)((B + 3) / 4)), dim3(64), 0, (hipStream_t)stream,\n"
@@ -1124,11 +1099,14 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
             << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
             << "                           stepIters, fallback, done, violFlag);\n"
             << "        return (int)hipGetLastError();\n    }\n";
-    src << "    (void)rich;\n"
-        << "    hipLaunchKernelGGL(csim_tran_sched_kernel, dim3(waves), dim3(64), 0, (hipStream_t)stream,\n"
-        << "                       params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
-        << "                       stepIters, fallback, done, violFlag);\n"
-        << "    return (int)hipGetLastError();\n}\n";
+    src << "    (void)rich; (void)waves;\n";
+    if (haveLinear)
+        src << "    return (int)hipErrorInvalidValue;   // the linear-circuit kernel needs its work area\n}\n";
+    else
+        src << "    hipLaunchKernelGGL(csim_tran_sched_kernel, dim3(waves), dim3(64), 0, (hipStream_t)stream,\n"
+            << "                       params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
+            << "                       stepIters, fallback, done, violFlag);\n"
+            << "    return (int)hipGetLastError();\n}\n";
     return src.str();
 }
 

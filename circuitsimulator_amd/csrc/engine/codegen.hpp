@@ -68,7 +68,7 @@ struct GeneratorOptions {
 };
 
 // bumped whenever the emitted code or the launcher ABI of a generated library changes
-constexpr int kGeneratorRevision = 16;
+constexpr int kGeneratorRevision = 17;
 
 // identifies (topology, constants, schedule); names the generated library
 uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch);
@@ -77,6 +77,12 @@ uint64_t scheduleHash(const csim_ir& ir, const ScheduleSet& set, const Generator
 struct CodegenStats {
     int nMul = 0, nFma = 0, nAddSub = 0, nRecip = 0, nCmp = 0, nDynU = 0, nLower = 0;
 };
+
+// codegen_linear.cpp: kernel for circuits without nonlinear devices (factor once per launch, substitute
+// once per step); "" when the circuit has MOSFETs or its iterate does not fit LDS.  workDoubles = doubles
+// per instance of the factor store the launcher needs, lanesPerWave = instances per workgroup.
+std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sc,
+                             int* workDoubles, int* lanesPerWave);
 
 // complete .hip translation unit: kernel + extern "C" launcher + metadata
 std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, const ScheduleSet& set,

@@ -1,0 +1,544 @@
+// codegen_linear.cpp -- generated transient kernel for LINEAR circuits (no MOSFETs): factor once per
+// launch, substitute once per time step, iterate the damped update.
+//
+// For a circuit without nonlinear devices the system of a time step does not depend on the iterate:
+// G is the same in every factorisation of a launch (dt is fixed), and the right-hand side is the same in
+// every Newton pass of a step (sources at t, history currents from the previous state).  The reference
+// nevertheless stamps, factors and substitutes in every pass (src/tanalisis.cpp:258-377) -- 16.9 times per
+// step on the N = 257 RC ladder of BASELINE configs[3].  Identical inputs give identical outputs, so this
+// kernel
+//   * factors G ONCE per launch with the recorded pivot order, verifying every pivot choice exactly as
+//     the other generated kernels do (a failed check hands the instance to the general kernel for the
+//     launch), and parks the multipliers, the U entries and the pivot reciprocals on a per-instance
+//     "tape" in global memory, written in the order in which a time step reads them
+//     ([workgroup][entry][lane]: consecutive entries are a constant stride apart, so the step's ~1800
+//     loads need no address arithmetic beyond an immediate offset, and a wave reads consecutive doubles);
+//   * per time step assembles the right-hand side, replays the forward elimination on it with the parked
+//     multipliers, back-substitutes, and keeps x_raw in LDS;
+//   * per Newton pass executes what remains of the reference's loop body: the damped update
+//     x += alpha (x_raw - x), the norm in index order and the convergence test (:365-376).  Pass counts
+//     are executed, not predicted.
+// One lane owns one instance (iterate and x_raw in LDS, lane-private columns).  Same deliberate
+// floating-point differences as the other generated kernels: FMA contraction, one Newton-refined
+// reciprocal per pivot.  Round 1 got the factorisation out of the loops only through hipcc's
+// loop-invariant code motion, at 13 KB of scratch per lane; this kernel needs none.
+#include "codegen.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <sstream>
+
+namespace csim {
+
+namespace {
+
+std::string lit(double x)
+{
+    char buf[64];
+    std::snprintf(buf, sizeof buf, "%a", x);
+    return std::string("(") + buf + ")";
+}
+
+// abstract value: structural zero, exact constant, or an expression evaluated at run time
+struct LV {
+    enum Kind { ZERO, CONST, DYN } kind = ZERO;
+    double c = 0.0;
+    std::string e;           // DYN: expression (a variable name or a load)
+    bool neg = false;
+    static LV konst(double x) { LV a; if (x == 0.0) return a; a.kind = CONST; a.c = x; return a; }
+    static LV dyn(const std::string& s, bool n = false) { LV a; a.kind = DYN; a.e = s; a.neg = n; return a; }
+    bool zero() const { return kind == ZERO; }
+};
+
+struct LGen {
+    std::ostringstream out;
+    std::string ind, prefix;
+    int tmp = 0;
+    std::string ref(const LV& a) const
+    {
+        if (a.kind == LV::CONST) return lit(a.c);
+        if (a.kind == LV::DYN) return a.neg ? "(-" + a.e + ")" : a.e;
+        return "0.0";
+    }
+    LV emit(const std::string& expr)
+    {
+        const std::string n = prefix + std::to_string(tmp++);
+        out << ind << "const double " << n << " = " << expr << ";\n";
+        return LV::dyn(n);
+    }
+    LV negate(LV a) { if (a.kind == LV::CONST) a.c = -a.c; else if (a.kind == LV::DYN) a.neg = !a.neg; return a; }
+    LV mul(const LV& a, const LV& b)
+    {
+        if (a.zero() || b.zero()) return LV();
+        if (a.kind == LV::CONST && b.kind == LV::CONST) return LV::konst(a.c * b.c);
+        if (a.kind == LV::CONST || b.kind == LV::CONST) {
+            const LV& k = a.kind == LV::CONST ? a : b;
+            const LV& d = a.kind == LV::CONST ? b : a;
+            if (k.c == 1.0) return d;
+            if (k.c == -1.0) return negate(d);
+            return emit(lit(k.c) + " * " + ref(d));
+        }
+        LV r = emit(a.e + " * " + b.e);
+        r.neg = a.neg != b.neg;
+        return r;
+    }
+    LV fnma(const LV& a, const LV& f, const LV& u)      // a - f*u
+    {
+        if (f.zero() || u.zero()) return a;
+        if (a.zero()) return negate(mul(f, u));
+        if (f.kind == LV::CONST && u.kind == LV::CONST) {
+            const double p = f.c * u.c;
+            if (a.kind == LV::CONST) return LV::konst(a.c - p);
+            return emit(ref(a) + " - " + lit(p));
+        }
+        const bool f1 = f.kind == LV::CONST && std::fabs(f.c) == 1.0, u1 = u.kind == LV::CONST && std::fabs(u.c) == 1.0;
+        if (f1 || u1) {
+            LV w = f1 ? u : f;
+            if ((f1 ? f.c : u.c) < 0) w = negate(w);
+            return emit(ref(a) + " - " + ref(w));
+        }
+        return emit(ref(a) + " - " + ref(f) + " * " + ref(u));
+    }
+    LV orderedSum(const std::vector<LV>& terms)           // the reference's accumulation order
+    {
+        bool allConst = true;
+        for (const LV& t : terms) allConst = allConst && t.kind != LV::DYN;
+        if (allConst) {
+            double acc = 0.0;
+            for (const LV& t : terms) acc = acc + (t.kind == LV::CONST ? t.c : 0.0);
+            return LV::konst(acc);
+        }
+        std::vector<LV> nz;
+        for (const LV& t : terms) if (!t.zero()) nz.push_back(t);
+        if (nz.size() == 1) return nz[0];
+        std::string e;
+        for (std::size_t i = 0; i < nz.size(); ++i) {
+            const LV& t = nz[i];
+            if (i == 0) { e = ref(t); continue; }
+            if (t.kind == LV::DYN) e = "(" + e + (t.neg ? " - " : " + ") + t.e + ")";
+            else e = "(" + e + " + " + lit(t.c) + ")";
+        }
+        return emit(e);
+    }
+};
+
+} // namespace
+
+// TRAN source value of element e into `target` (shared with codegen.cpp): SourceSpec::evalTran with
+// TranWaveform::eval (reference include/sim.hpp:75-143,160-162).  P(o) = expression of parameter slot o.
+void emitTranSourceValue(std::ostream& src, const std::string& i2, const csim_ir& ir, int e,
+                         const std::function<std::string(int)>& P, const std::string& target)
+{
+    const csim_consts& K = ir.k;
+    if (ir.wave[e] == CSIM_WAVE_SIN) {
+        src << i2 << "if (tNow < " << P(4) << ") " << target << " = " << P(0) << " + " << P(1) << ";\n"
+            << i2 << "else " << target << " = " << P(0) << " + (" << P(1) << " + " << P(2)
+            << " * sin((2.0 * " << lit(K.pi) << " * " << P(3) << ") * (tNow - " << P(4) << ") + " << P(5) << "));\n";
+    } else if (ir.wave[e] == CSIM_WAVE_PULSE) {
+        src << i2 << "{\n"
+            << i2 << "    const double v1 = " << P(1) << ", v2 = " << P(2) << ", td = " << P(3) << ", tr = " << P(4)
+            << ", tf = " << P(5) << ", ton = " << P(6) << ", per = " << P(7) << ";\n"
+            << i2 << "    double w;\n"
+            << i2 << "    if (per <= 0.0) {\n"
+            << i2 << "        const double tau = tNow - td;\n"
+            << i2 << "        if (tau <= 0.0) w = v1;\n"
+            << i2 << "        else if (tau < tr) w = v1 + clamp01_cg(tau / tr) * (v2 - v1);\n"
+            << i2 << "        else if (tau < tr + ton) w = v2;\n"
+            << i2 << "        else w = v2 + clamp01_cg((tau - (tr + ton)) / tf) * (v1 - v2);\n"
+            << i2 << "    } else if (tNow < td) {\n"
+            << i2 << "        w = v1;\n"
+            << i2 << "    } else {\n"
+            << i2 << "        double tau = fmod(tNow - td, per);\n"
+            << i2 << "        if (tau < 0.0) tau += per;\n"
+            << i2 << "        if (tau < tr) w = v1 + (v2 - v1) * clamp01_cg(tau / tr);\n"
+            << i2 << "        else if (tau < tr + ton) w = v2;\n"
+            << i2 << "        else if (tau < tr + ton + tf) w = v2 + (v1 - v2) * clamp01_cg((tau - (tr + ton)) / tf);\n"
+            << i2 << "        else w = v1;\n"
+            << i2 << "    }\n"
+            << i2 << "    " << target << " = " << P(0) << " + w;\n"
+            << i2 << "}\n";
+    } else if (ir.wave[e] == CSIM_WAVE_PWL) {
+        const int n = ir.wave_n[e];
+        auto PT = [&](int i) { return P(1 + i); };
+        auto PV = [&](int i) { return P(1 + n + i); };
+        src << i2 << "{\n" << i2 << "    double w;\n";
+        if (n <= 0) {
+            src << i2 << "    w = 0.0;\n";
+        } else {
+            src << i2 << "    if (tNow <= " << PT(0) << ") w = " << PV(0) << ";\n"
+                << i2 << "    else if (tNow >= " << PT(n - 1) << ") w = " << PV(n - 1) << ";\n";
+            for (int i = 0; i + 1 < n; ++i)
+                src << i2 << "    else if (tNow > " << PT(i) << " && tNow <= " << PT(i + 1) << ") { const double ta = " << PT(i)
+                    << ", tb = " << PT(i + 1) << ", va = " << PV(i) << ", vb = " << PV(i + 1)
+                    << "; w = va + (vb - va) * ((tNow - ta) / (tb - ta)); }\n";
+            src << i2 << "    else w = " << PV(n - 1) << ";\n";
+        }
+        src << i2 << "    " << target << " = " << P(0) << " + w;\n" << i2 << "}\n";
+    } else {
+        src << i2 << target << " = " << P(0) << " + 0.0;\n";
+    }
+}
+
+// Emits csim_tran_linear_kernel.  workDoubles = doubles per instance of the factor store the launcher
+// must be given; lanesPerWave = instances per workgroup (iterate + x_raw must fit one CU's LDS).
+std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sc,
+                             int* workDoubles, int* lanesPerWave)
+{
+    const int N = ir.n_unknowns;
+    const csim_consts& K = ir.k;
+    if (ir.has_nonlinear || N <= 0) return std::string();
+    int LPW = 64;
+    while (LPW >= 8 && 2LL * N * 8 * LPW > 160 * 1024) LPW /= 2;
+    if (LPW < 8) return std::string();
+    const int LD = ap.LD;
+    const GatherPlan& gpl = ap.tran;
+
+    // Operands that the per-step block takes from the factor block travel over the tape.  While the code is
+    // generated they are placeholders: "@L<h>@" where handle h is read, "@S<h>@" where its value (the local
+    // `pk`) is stored.  Afterwards the reads are numbered in the order in which they appear in the per-step
+    // block and every handle is stored to all the positions that read it.
+    int nHandles = 0;
+    auto rd = [](int h) { return "@L" + std::to_string(h) + "@"; };
+    auto st = [](int h) { return "@S" + std::to_string(h) + "@"; };
+    // ---- terms.  Launch constants are written to the store once (factor block) and re-read where needed.
+    std::vector<LV> termF(static_cast<std::size_t>(ap.nTerms)), termS(static_cast<std::size_t>(ap.nTerms));
+    std::ostringstream consts;                            // code that fills the launch constants
+    std::ostringstream stepCode;                          // per-step source values
+    termF[static_cast<std::size_t>(ap.termOne)] = termS[static_cast<std::size_t>(ap.termOne)] = LV::konst(1.0);
+    termF[static_cast<std::size_t>(ap.termGmin)] = termS[static_cast<std::size_t>(ap.termGmin)] = LV::konst(K.tran_gmin);
+    auto PX = [](int slot) { return "params[" + std::to_string(slot) + "LL * SB + bb]"; };
+    for (int e = 0; e < ir.n_elems; ++e) {
+        const int s = ir.param_slot[e], tb = ap.termBase[static_cast<std::size_t>(e)];
+        const int32_t* q = ir.eq + 4 * e;
+        auto X = [&](int eq) { return eq >= 0 ? "XL(" + std::to_string(eq) + ")" : std::string("0.0"); };
+        switch (ir.kind[e]) {
+            case CSIM_R:
+                // used by the factorisation only (once per launch): evaluated where a G entry needs it
+                termF[static_cast<std::size_t>(tb + T_R_G)] = LV::dyn("lin_ginv(" + PX(s) + ")");
+                break;
+            case CSIM_C: {
+                const int h = nHandles++;
+                consts << "    { const double pk = lin_gc(" << PX(s) << ", dt); " << st(h) << " }\n";
+                termF[static_cast<std::size_t>(tb + T_C_GC)] = LV::dyn("lin_gc(" + PX(s) + ", dt)");
+                // history current -Gc * vPrev (tanalisis.cpp:77), evaluated where the right-hand side needs it:
+                // the substitution runs at the start of the step, when XL still holds the previous state
+                const std::string v = (q[0] >= 0 && q[1] >= 0) ? "(" + X(q[0]) + " - " + X(q[1]) + ")"
+                                      : (q[0] >= 0 ? X(q[0]) : (q[1] >= 0 ? "(-" + X(q[1]) + ")" : std::string("0.0")));
+                termS[static_cast<std::size_t>(tb + T_C_IH)] = LV::dyn("(-" + rd(h) + " * " + v + ")");
+                break;
+            }
+            case CSIM_L: {
+                const int h = nHandles++;
+                consts << "    { const double L = " << PX(s) << "; viol = viol || !(L > 0.0); const double pk = L / dt; " << st(h) << " }\n";
+                termF[static_cast<std::size_t>(tb + T_L_REQ)] = LV::dyn("(" + PX(s) + " / dt)");
+                termF[static_cast<std::size_t>(tb + T_L_ONE)] = LV::konst(1.0);
+                const int kb = ir.branch_eq[e];
+                termS[static_cast<std::size_t>(tb + T_L_VH)] = LV::dyn("(-" + rd(h) + " * " + X((kb >= 0 && kb < N) ? kb : -1) + ")");
+                break;
+            }
+            case CSIM_V: case CSIM_I: {
+                const std::string name = "sv" + std::to_string(e);
+                stepCode << "        double " << name << ";\n";
+                // parameters are re-read per step through an offset the compiler cannot fold (see codegen.cpp)
+                emitTranSourceValue(stepCode, "        ", ir, e,
+                                    [&](int o) { return "params[" + std::to_string(s + o) + "LL * SB + bb + vo]"; }, name);
+                termS[static_cast<std::size_t>(tb + T_SRC_VAL)] = LV::dyn(name);
+                break;
+            }
+            default: break;
+        }
+    }
+
+    // ---- factor block: assembly of G (lazy) + elimination with the recorded pivots (solver.hpp:46-77)
+    LGen gf;
+    gf.ind = "    ";
+    gf.prefix = "vf";
+    std::vector<std::vector<LV>> M(static_cast<std::size_t>(N), std::vector<LV>(static_cast<std::size_t>(N)));
+    std::vector<std::vector<std::vector<LV>>> pend(static_cast<std::size_t>(N), std::vector<std::vector<LV>>(static_cast<std::size_t>(N)));
+    for (int n = 0; n < gpl.nnzG(); ++n) {
+        std::vector<LV> terms;
+        for (int c = gpl.gPtr[static_cast<std::size_t>(n)]; c < gpl.gPtr[static_cast<std::size_t>(n + 1)]; ++c) {
+            const int con = gpl.gCon[static_cast<std::size_t>(c)];
+            LV t = termF[static_cast<std::size_t>(con >> 1)];
+            terms.push_back((con & 1) ? gf.negate(t) : t);
+        }
+        const int pos = gpl.gPos[static_cast<std::size_t>(n)];
+        bool allConst = true;
+        for (const LV& t : terms) allConst = allConst && t.kind != LV::DYN;
+        if (allConst) M[static_cast<std::size_t>(pos / LD)][static_cast<std::size_t>(pos % LD)] = gf.orderedSum(terms);
+        else { pend[static_cast<std::size_t>(pos / LD)][static_cast<std::size_t>(pos % LD)] = terms; M[static_cast<std::size_t>(pos / LD)][static_cast<std::size_t>(pos % LD)] = LV::dyn("?"); }
+    }
+    auto at = [&](int r, int c) -> LV& {
+        auto& p = pend[static_cast<std::size_t>(r)][static_cast<std::size_t>(c)];
+        LV& slot = M[static_cast<std::size_t>(r)][static_cast<std::size_t>(c)];
+        if (!p.empty()) { slot = gf.orderedSum(p); p.clear(); }
+        return slot;
+    };
+    auto park = [&](const LV& v) -> LV {                   // run-time value -> the tape; constants stay constants
+        if (v.kind != LV::DYN) return v;
+        const int h = nHandles++;
+        gf.out << gf.ind << "{ const double pk = " << gf.ref(v) << "; " << st(h) << " }\n";
+        return LV::dyn(rd(h));
+    };
+    struct FwdOp { int i, k; LV f; };
+    std::vector<FwdOp> fwd;                                // b_i -= f * b_k, in elimination order
+    std::vector<int> swapWith(static_cast<std::size_t>(N));
+    std::vector<LV> rinv(static_cast<std::size_t>(N));
+    for (int k = 0; k < N; ++k) {
+        const int p = sc.pivotPos[static_cast<std::size_t>(k)];
+        swapWith[static_cast<std::size_t>(k)] = p;
+        const LV pv = at(p, k);
+        gf.out << gf.ind << "// column " << k << ": pivot row position " << p << "\n";
+        // scheduling barriers: without them hipcc hoists hundreds of loads to the top of these long
+        // straight-line blocks and spills what it hoisted (16 KB of scratch per lane, measured)
+        if ((k % 2) == 0) gf.out << gf.ind << "__builtin_amdgcn_sched_barrier(0);\n";
+        if (pv.zero()) {
+            gf.out << gf.ind << "pvF = true;   // scheduled pivot is a structural zero\n";
+        } else {
+            // first row attaining the column maximum (solver.hpp:48-56), >= 1e-15 (:58-61)
+            const std::string absP = pv.kind == LV::CONST ? lit(std::fabs(pv.c)) : "fabs(" + pv.e + ")";
+            std::string mb, ma;
+            bool contradiction = pv.kind == LV::CONST && std::fabs(pv.c) < K.lu_eps;
+            for (int i = k; i < N; ++i) {
+                if (i == p) continue;
+                const LV& ai = at(i, k);
+                if (ai.zero()) continue;
+                if (ai.kind == LV::CONST && pv.kind == LV::CONST) {
+                    const bool ok = i < p ? std::fabs(pv.c) > std::fabs(ai.c) : std::fabs(pv.c) >= std::fabs(ai.c);
+                    if (!ok) contradiction = true;
+                    continue;
+                }
+                const std::string absI = ai.kind == LV::CONST ? lit(std::fabs(ai.c)) : "fabs(" + ai.e + ")";
+                std::string& m = (i < p) ? mb : ma;
+                m = m.empty() ? absI : "fmax(" + m + ", " + absI + ")";
+            }
+            if (contradiction) gf.out << gf.ind << "pvF = true;\n";
+            else {
+                std::string e;
+                if (pv.kind == LV::DYN) e = ma.empty() ? "(" + absP + " >= " + lit(K.lu_eps) + ")" : "(" + absP + " >= fmax(" + ma + ", " + lit(K.lu_eps) + "))";
+                else if (!ma.empty()) e = "(" + absP + " >= " + ma + ")";
+                if (!mb.empty()) e += std::string(e.empty() ? "" : " & ") + "(" + absP + " > " + mb + ")";
+                if (!e.empty()) gf.out << gf.ind << "pvF |= !(" << e << ");\n";
+            }
+        }
+        if (p != k) { std::swap(M[static_cast<std::size_t>(p)], M[static_cast<std::size_t>(k)]); std::swap(pend[static_cast<std::size_t>(p)], pend[static_cast<std::size_t>(k)]); }
+        const LV piv = at(k, k);
+        LV r;
+        if (piv.kind == LV::CONST) r = LV::konst(1.0 / piv.c);
+        else if (piv.kind == LV::DYN) r = gf.emit("rcp_nr(" + gf.ref(piv) + ")");
+        for (int i = k + 1; i < N; ++i) {
+            const LV aik = at(i, k);
+            if (aik.zero()) continue;
+            const LV f = gf.mul(aik, r);                                  // multiplier (solver.hpp:71)
+            for (int j = k + 1; j < N; ++j) {
+                if (M[static_cast<std::size_t>(k)][static_cast<std::size_t>(j)].zero()) continue;
+                const LV u = at(k, j);
+                if (u.zero()) continue;
+                const LV a = at(i, j);
+                M[static_cast<std::size_t>(i)][static_cast<std::size_t>(j)] = gf.fnma(a, f, u);   // :74
+            }
+            M[static_cast<std::size_t>(i)][static_cast<std::size_t>(k)] = LV();
+            fwd.push_back({i, k, park(f)});
+        }
+        // row k is final: park its run-time entries and the reciprocal
+        for (int j = k + 1; j < N; ++j) {
+            if (M[static_cast<std::size_t>(k)][static_cast<std::size_t>(j)].zero()) continue;
+            M[static_cast<std::size_t>(k)][static_cast<std::size_t>(j)] = park(at(k, j));
+        }
+        rinv[static_cast<std::size_t>(k)] = park(r);
+    }
+
+    // ---- per-step block: right-hand side, forward elimination replayed, back substitution
+    LGen gs;
+    gs.ind = "            ";
+    gs.prefix = "vs";
+    std::vector<LV> rhs(static_cast<std::size_t>(N));
+    std::vector<std::vector<LV>> rpend(static_cast<std::size_t>(N));
+    for (int n = 0; n < gpl.nnzI(); ++n) {
+        std::vector<LV> terms;
+        for (int c = gpl.iPtr[static_cast<std::size_t>(n)]; c < gpl.iPtr[static_cast<std::size_t>(n + 1)]; ++c) {
+            const int con = gpl.iCon[static_cast<std::size_t>(c)];
+            LV t = termS[static_cast<std::size_t>(con >> 1)];
+            terms.push_back((con & 1) ? gs.negate(t) : t);
+        }
+        rpend[static_cast<std::size_t>(gpl.iRow[static_cast<std::size_t>(n)])] = terms;
+        rhs[static_cast<std::size_t>(gpl.iRow[static_cast<std::size_t>(n)])] = LV::dyn("?");
+    }
+    auto bAt = [&](int r) -> LV& {
+        if (!rpend[static_cast<std::size_t>(r)].empty()) { rhs[static_cast<std::size_t>(r)] = gs.orderedSum(rpend[static_cast<std::size_t>(r)]); rpend[static_cast<std::size_t>(r)].clear(); }
+        return rhs[static_cast<std::size_t>(r)];
+    };
+    {
+        std::size_t op = 0;
+        for (int k = 0; k < N; ++k) {
+            const int p = swapWith[static_cast<std::size_t>(k)];
+            if (p != k) { std::swap(rhs[static_cast<std::size_t>(p)], rhs[static_cast<std::size_t>(k)]); std::swap(rpend[static_cast<std::size_t>(p)], rpend[static_cast<std::size_t>(k)]); }
+            if ((k % 4) == 0) gs.out << gs.ind << "__builtin_amdgcn_sched_barrier(0);\n";
+            for (; op < fwd.size() && fwd[op].k == k; ++op) {
+                const LV bk = bAt(k);
+                if (bk.zero()) continue;
+                const LV bi = bAt(fwd[op].i);
+                rhs[static_cast<std::size_t>(fwd[op].i)] = gs.fnma(bi, fwd[op].f, bk);
+            }
+        }
+    }
+    gs.out << gs.ind << "// back substitution (solver.hpp:116-128); x_raw goes to LDS\n";
+    std::vector<LV> xr(static_cast<std::size_t>(N));
+    for (int i = N - 1; i >= 0; --i) {
+        if ((i % 4) == 0) gs.out << gs.ind << "__builtin_amdgcn_sched_barrier(0);\n";
+        LV sum = bAt(i);
+        for (int j = i + 1; j < N; ++j) {
+            const LV& u = M[static_cast<std::size_t>(i)][static_cast<std::size_t>(j)];
+            if (u.zero()) continue;
+            sum = gs.fnma(sum, u, xr[static_cast<std::size_t>(j)]);
+        }
+        LV x = gs.mul(sum, rinv[static_cast<std::size_t>(i)]);
+        if (x.kind == LV::DYN && (x.e.compare(0, 2, "vs") != 0 || x.neg)) x = gs.emit(gs.ref(x));    // a named value, read once below
+        gs.out << gs.ind << "XRL(" << i << ") = " << gs.ref(x) << ";\n";
+        xr[static_cast<std::size_t>(i)] = x;
+    }
+
+    // ---- number the tape in the order of the per-step block's reads
+    std::string stepText = gs.out.str(), factorText = consts.str() + "    // factorisation, once per launch: G does not depend on the iterate or on time\n    bool pvF = false;\n" + gf.out.str();
+    std::vector<std::vector<int>> uses(static_cast<std::size_t>(nHandles));
+    int nTape = 0;
+    {
+        std::string outText;
+        std::size_t i = 0;
+        while (i < stepText.size()) {
+            const std::size_t a = stepText.find("@L", i);
+            if (a == std::string::npos) { outText += stepText.substr(i); break; }
+            const std::size_t b = stepText.find('@', a + 2);
+            const int h = std::atoi(stepText.substr(a + 2, b - a - 2).c_str());
+            outText += stepText.substr(i, a - i) + "TP(" + std::to_string(nTape) + ")";
+            uses[static_cast<std::size_t>(h)].push_back(nTape++);
+            i = b + 1;
+        }
+        stepText = outText;
+        outText.clear();
+        i = 0;
+        while (i < factorText.size()) {
+            const std::size_t a = factorText.find("@S", i);
+            if (a == std::string::npos) { outText += factorText.substr(i); break; }
+            const std::size_t b = factorText.find('@', a + 2);
+            const int h = std::atoi(factorText.substr(a + 2, b - a - 2).c_str());
+            outText += factorText.substr(i, a - i);
+            for (int n : uses[static_cast<std::size_t>(h)]) outText += "TW(" + std::to_string(n) + ") = pk; ";
+            i = b + 1;
+        }
+        factorText = outText;
+    }
+    if (nTape == 0) nTape = 1;
+
+    const int slowIters = slowStepIters(K.tran_tol, K.tran_alpha, K.tran_max_iters);
+    std::ostringstream o;
+    o << "// ---- linear circuit: factor once per launch, substitute once per step (codegen_linear.cpp)\n"
+      << "__device__ __forceinline__ double lin_ginv(double R) { return (R == 0.0) ? 0.0 : 1.0 / R; }            // element.cpp:20-24\n"
+      << "__device__ __forceinline__ double lin_gc(double C, double dt) { return (C > 0.0 && dt > 0.0) ? C / dt : 0.0; }   // tanalisis.cpp:65-67\n"
+      << "// pivot schedule: " << (sc.str().empty() ? std::string("-") : sc.str()) << "\n"
+      << "extern \"C\" __global__ void __launch_bounds__(64)\n"
+      << "csim_tran_linear_kernel(const double* __restrict__ params, int B, double dt, long long stepFirst,\n"
+      << "                        long long nSteps, const int* __restrict__ probeEq, int nProbe, int outStride,\n"
+      << "                        double* __restrict__ wave, double* __restrict__ xio, long long* __restrict__ iters,\n"
+      << "                        unsigned* __restrict__ status, int* __restrict__ stepIters,\n"
+      << "                        unsigned char* __restrict__ fallback, int* __restrict__ done,\n"
+      << "                        int* __restrict__ violFlag, double* __restrict__ work)\n{\n"
+      << "    __shared__ double ldsl[" << 2 * N * LPW << "];      // iterate and x_raw, one private column per lane\n"
+      << "    const int lane = threadIdx.x;                      // " << LPW << " instances per workgroup\n"
+      << "    const int b = blockIdx.x * " << LPW << " + lane;\n"
+      << "    const bool inb = b < B;\n"
+      << "    const long long bb = inb ? b : B - 1;\n"
+      << "    const long long SB = B;\n"
+      << "    const bool splitFlag = outStride < 0;             // never true; opaque to the compiler\n"
+      << "    if (!__any(inb && done[bb] < nSteps)) return;\n"
+      << "#define XL(i) ldsl[(i) * " << LPW << " + lane]\n"
+      << "#define XRL(i) ldsl[(" << N << " + (i)) * " << LPW << " + lane]\n"
+      << "    // the tape: [workgroup][entry][lane]; TW = as written by the factor block, TP = as read inside the time\n"
+      << "    // loop, through a base that carries an always-zero offset the compiler cannot see through (else it\n"
+      << "    // hoists ~1800 loop-invariant loads or their addresses out of the time loop and spills them)\n"
+      << "    double* const tapeW = work + ((long long)blockIdx.x * " << nTape << ") * " << LPW << " + lane;\n"
+      << "#define TW(n) tapeW[(n) * " << LPW << "]\n"
+      << "#define TP(n) tapeR[(n) * " << LPW << "]\n"
+      << "    bool viol = false;\n"
+      << "    {\n        const double* xin = xio + bb;\n#pragma unroll 1\n"
+      << "        for (int i = 0; i < " << N << "; ++i, xin += SB) XL(i) = *xin;\n    }\n"
+      << "    // launch constants (tanalisis.cpp:65-67,296) and the factors -> the tape\n"
+      << factorText
+      << "    viol = viol || pvF;\n"
+      << "    unsigned st = inb ? status[bb] : 0u;\n"
+      << "    bool dead = !inb || (st & ST_TRAN_NONFINITE) != 0u;\n"
+      << "    long long itTotal = 0;\n"
+      << "    long long sdone = (inb && !dead) ? (long long)done[bb] : nSteps;\n"
+      << "    if (stepFirst == 0 && sdone == 0 && wave && inb)\n"
+      << "        for (int q = 0; q < nProbe; ++q) wave[((long long)q) * SB + b] = XL(probeEq[q]);\n"
+      << "    int smin = (int)(sdone < nSteps ? sdone + 1 : nSteps + 1);\n"
+      << "    for (int m = " << LPW / 2 << "; m >= 1; m >>= 1) { const int ot = __shfl_xor(smin, m); smin = ot < smin ? ot : smin; }   // active lanes only\n"
+      << "    smin = __builtin_amdgcn_readfirstlane(smin);\n"
+      << "    for (long long s = smin; s <= nSteps; ++s) {\n"
+      << "        if (!__any(!dead && !viol && sdone < nSteps)) break;\n"
+      << "        const bool live = !dead && !viol && sdone + 1 == s;\n"
+      << "        const long long gstep = stepFirst + s;\n"
+      << "        const double tNow = (double)(int)gstep * dt;\n"
+      << "        const long long vo = splitFlag ? s : 0LL;\n"
+      << "        const double* const tapeR = tapeW + vo;\n"
+      << "        if (live) {     // checkpoint: state at the start of this step (what a violated instance hands over)\n"
+      << "            double* ck = xio + b;\n#pragma unroll 4\n"
+      << "            for (int i = 0; i < " << N << "; ++i, ck += SB) *ck = XL(i);\n"
+      << "        }\n"
+      << stepCode.str()
+      << "        {   // one solve per step: the right-hand side is the same in every Newton pass of the step\n"
+      << stepText
+      << "        }\n"
+      << "        bool active = live;\n"
+      << "        int it = 0;\n"
+      << "        for (int iter = 0; iter < " << K.tran_max_iters << "; ++iter) {\n"
+      << "            if (!__any(active)) break;\n"
+      << "            double ss = 0.0;     // damped update and norm in index order (tanalisis.cpp:365-366)\n"
+      << "#pragma unroll 4\n"
+      << "            for (int i = 0; i < " << N << "; ++i) {\n"
+      << "                const double xo = XL(i);\n"
+      << "                const double xn = xo + " << lit(K.tran_alpha) << " * (XRL(i) - xo);\n"
+      << "                const double d = xn - xo;\n"
+      << "                ss += d * d;\n"
+      << "                if (active) XL(i) = xn;\n"
+      << "            }\n"
+      << "            const double err = sqrt(ss);\n"
+      << "            if (active) {\n"
+      << "                if (!(ss < 1.0e300)) { viol = true; active = false; }      // non-finite solve: the general kernel classifies it\n"
+      << "                else {\n"
+      << "                    ++it;\n"
+      << "                    if (err < " << lit(K.tran_tol) << ") active = false;\n"
+      << "                    else if (iter >= " << (slowIters - 1) << ") { viol = true; active = false; }   // slow step: plan.hpp slowStepIters\n"
+      << "                }\n"
+      << "            }\n"
+      << "        }\n"
+      << "        if (live && !viol) {\n"
+      << "            itTotal += it;\n"
+      << "            if (stepIters) stepIters[(s - 1) * SB + b] = it;\n"
+      << "            if (wave && (gstep % outStride) == 0) {\n"
+      << "                const long long row = gstep / outStride;\n"
+      << "                for (int q = 0; q < nProbe; ++q) wave[(row * nProbe + q) * SB + b] = XL(probeEq[q]);\n"
+      << "            }\n"
+      << "            sdone = s;\n"
+      << "        }\n"
+      << "    }\n"
+      << "    if (inb) {\n"
+      << "        if (viol) { fallback[b] = 1; *violFlag = 1; }   // xio holds the checkpoint of the step that failed\n"
+      << "        else {\n"
+      << "            double* xo = xio + b;\n#pragma unroll 1\n"
+      << "            for (int i = 0; i < " << N << "; ++i, xo += SB) *xo = XL(i);\n"
+      << "        }\n"
+      << "        iters[b] += itTotal;\n"
+      << "        status[b] |= st;\n"
+      << "        done[b] = (int)sdone;\n"
+      << "    }\n"
+      << "#undef XL\n#undef XRL\n#undef TW\n#undef TP\n"
+      << "}\n\n";
+    if (workDoubles) *workDoubles = nTape;
+    if (lanesPerWave) *lanesPerWave = LPW;
+    return o.str();
+}
+
+} // namespace csim

@@ -141,6 +141,8 @@ void adoptScheduleTable(csim_engine* eng, void* lib)
     typedef int (*LanesFn)(void);
     LanesFn lanesFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_group_lanes"));
     eng->schedGroupLanes = lanesFn ? lanesFn() : 0;
+    LanesFn workFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_work_doubles"));
+    eng->schedWorkDoubles = workFn ? workFn() : 0;
     // DC operating-point kernel, present when the library was generated with "dc" schedules
     eng->schedDcLaunch = nullptr;
     if (AltsFn dcAlts = reinterpret_cast<AltsFn>(dlsym(lib, "csim_sched_dc_alts"))) {
@@ -264,6 +266,7 @@ void csim_engine_destroy(csim_engine* eng)
     for (void* p : eng->owned) (void)hipFree(p);
     if (eng->dFallback) (void)hipFree(eng->dFallback);
     if (eng->dDone) (void)hipFree(eng->dDone);
+    if (eng->dSchedWork) (void)hipFree(eng->dSchedWork);
     if (eng->dViolFlag) (void)hipFree(eng->dViolFlag);
     if (eng->hViolFlag) (void)hipHostFree(eng->hViolFlag);
     if (eng->dKnownAlts) (void)hipFree(eng->dKnownAlts);
@@ -468,11 +471,19 @@ int csim_tran_batch_dev(csim_engine* eng, const double* d_params, int32_t B, dou
     }
     HIPCHK(hipMemsetAsync(eng->dFallback, 0, (size_t)B, hs));
     HIPCHK(hipMemsetAsync(eng->dDone, 0, sizeof(int32_t) * (size_t)B, hs));
+    if (eng->schedWorkDoubles > 0 && eng->schedWorkCap < B) {      // factor store of the linear-circuit kernel
+        if (eng->dSchedWork) HIPCHK(hipFree(eng->dSchedWork));
+        eng->dSchedWork = nullptr;
+        eng->schedWorkCap = 0;
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dSchedWork), sizeof(double) * (size_t)eng->schedWorkDoubles * ((size_t)B + 64)));   // whole workgroups
+        eng->schedWorkCap = B;
+    }
     auto scheduled = [&](bool* anyUnfinished) -> int {
         HIPCHK(hipMemsetAsync(eng->dViolFlag, 0, sizeof(int32_t), hs));
         const int lrc = eng->schedLaunch(d_params, B, tstep, step_first, n_steps, dProbe, np, os, d_wave, d_x,
                                          reinterpret_cast<long long*>(d_iters), d_status, d_step_iters,
-                                         eng->dFallback, eng->dDone, eng->dViolFlag, stream, schedVariantFor(eng, B));
+                                         eng->dFallback, eng->dDone, eng->dViolFlag, eng->dSchedWork, stream,
+                                         schedVariantFor(eng, B));
         if (lrc != 0) { setError(std::string("scheduled kernel launch: ") + hipGetErrorString((hipError_t)lrc)); return CSIM_ERR_HIP; }
         return readViolFlag(eng, hs, anyUnfinished);
     };

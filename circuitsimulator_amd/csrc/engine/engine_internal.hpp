@@ -44,13 +44,16 @@ struct csim_engine {
 
     // circuit-specialised transient kernel (side library libcsim_sched_<topology>.so)
     typedef int (*SchedLaunchFn)(const double*, int, double, long long, long long, const int*, int, int,
-                                 double*, double*, long long*, unsigned*, int*, unsigned char*, int*, int*, void*, int);
+                                 double*, double*, long long*, unsigned*, int*, unsigned char*, int*, int*, double*, void*, int);
     // DC operating point of the same library (nullptr: the library carries no DC schedule)
     typedef int (*SchedDcLaunchFn)(const double*, int, double*, int*, unsigned*, unsigned char*, int*, void*);
     void* schedLib = nullptr;
     SchedLaunchFn schedLaunch = nullptr;
     SchedDcLaunchFn schedDcLaunch = nullptr;
     std::string schedInfo;
+    int schedWorkDoubles = 0;              // per-instance doubles of the work area the library's launcher wants
+    double* dSchedWork = nullptr;
+    int schedWorkCap = 0;                  // instances
     int schedGroupLanes = 0;               // 16 when the library also carries the sixteen-lanes-per-instance kernel
     int32_t* dKnownAlts = nullptr;         // [nKnownAlts][N] pivot sequences the loaded kernel carries
     int nKnownAlts = 0;
