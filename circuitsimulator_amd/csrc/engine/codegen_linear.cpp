@@ -24,6 +24,7 @@
 // loop-invariant code motion, at 13 KB of scratch per lane; this kernel needs none.
 #include "codegen.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -430,6 +431,52 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
         }
         factorText = outText;
     }
+    // The step reads the tape strictly in order, one miss of ~700 cycles each if it waits for every entry
+    // where it is used (measured: 454 us per step on the N = 257 ladder, 1539 sequential misses).  So the
+    // entries are loaded into registers two chunks of 48 ahead of their use: loads of chunk c+2 are issued
+    // where chunk c is first needed, and the scheduling barriers keep them there.
+    {
+        const int chunk = 48;
+        std::vector<std::string> lines;
+        {
+            std::size_t i = 0;
+            while (i < stepText.size()) {
+                const std::size_t e = stepText.find('\n', i);
+                lines.push_back(stepText.substr(i, (e == std::string::npos ? stepText.size() : e) - i));
+                if (e == std::string::npos) break;
+                i = e + 1;
+            }
+        }
+        const int nChunks = (nTape + chunk - 1) / chunk;
+        std::vector<int> firstLine(static_cast<std::size_t>(nChunks), -1);
+        for (std::size_t l = 0; l < lines.size(); ++l) {
+            std::size_t at = 0;
+            while ((at = lines[l].find("TP(", at)) != std::string::npos) {
+                const int n = std::atoi(lines[l].c_str() + at + 3);
+                if (firstLine[static_cast<std::size_t>(n / chunk)] < 0) firstLine[static_cast<std::size_t>(n / chunk)] = static_cast<int>(l);
+                at += 3;
+            }
+        }
+        auto loadsOf = [&](int c) {
+            std::string t;
+            for (int n = c * chunk; n < std::min(nTape, (c + 1) * chunk); ++n)
+                t += gs.ind + "const double tq" + std::to_string(n) + " = TP(" + std::to_string(n) + ");\n";
+            return t;
+        };
+        std::string outText = loadsOf(0) + (nChunks > 1 ? loadsOf(1) : std::string());
+        for (std::size_t l = 0; l < lines.size(); ++l) {
+            for (int c = 0; c + 2 < nChunks; ++c)
+                if (firstLine[static_cast<std::size_t>(c)] == static_cast<int>(l)) outText += loadsOf(c + 2);
+            std::string ln = lines[l];
+            std::size_t at = 0;
+            while ((at = ln.find("TP(", at)) != std::string::npos) {
+                const std::size_t close = ln.find(')', at);
+                ln = ln.substr(0, at) + "tq" + ln.substr(at + 3, close - at - 3) + ln.substr(close + 1);
+            }
+            outText += ln + "\n";
+        }
+        stepText = outText;
+    }
     if (nTape == 0) nTape = 1;
 
     const int slowIters = slowStepIters(K.tran_tol, K.tran_alpha, K.tran_max_iters);
@@ -445,7 +492,7 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
       << "                        unsigned* __restrict__ status, int* __restrict__ stepIters,\n"
       << "                        unsigned char* __restrict__ fallback, int* __restrict__ done,\n"
       << "                        int* __restrict__ violFlag, double* __restrict__ work)\n{\n"
-      << "    __shared__ double ldsl[" << 2 * N * LPW << "];      // iterate and x_raw, one private column per lane\n"
+      << "    __shared__ __attribute__((aligned(16))) double ldsl[" << 2 * N * LPW << "];      // iterate and x_raw, one private column per lane\n"
       << "    const int lane = threadIdx.x;                      // " << LPW << " instances per workgroup\n"
       << "    const int b = blockIdx.x * " << LPW << " + lane;\n"
       << "    const bool inb = b < B;\n"
@@ -453,8 +500,9 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
       << "    const long long SB = B;\n"
       << "    const bool splitFlag = outStride < 0;             // never true; opaque to the compiler\n"
       << "    if (!__any(inb && done[bb] < nSteps)) return;\n"
-      << "#define XL(i) ldsl[(i) * " << LPW << " + lane]\n"
-      << "#define XRL(i) ldsl[(" << N << " + (i)) * " << LPW << " + lane]\n"
+      << "    // (x_i, x_raw_i) of one lane are neighbours: the damped pass reads both with one ds_read_b128\n"
+      << "#define XL(i) ldsl[((i) * " << LPW << " + lane) * 2]\n"
+      << "#define XRL(i) ldsl[((i) * " << LPW << " + lane) * 2 + 1]\n"
       << "    // the tape: [workgroup][entry][lane]; TW = as written by the factor block, TP = as read inside the time\n"
       << "    // loop, through a base that carries an always-zero offset the compiler cannot see through (else it\n"
       << "    // hoists ~1800 loop-invariant loads or their addresses out of the time loop and spills them)\n"
@@ -496,13 +544,17 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
       << "        for (int iter = 0; iter < " << K.tran_max_iters << "; ++iter) {\n"
       << "            if (!__any(active)) break;\n"
       << "            double ss = 0.0;     // damped update and norm in index order (tanalisis.cpp:365-366)\n"
-      << "#pragma unroll 4\n"
+      << "            // one wave per CU (the LDS holds 2 x " << N << " doubles per lane): the LDS round trips of this loop\n"
+      << "            // are hidden by instruction-level parallelism only, hence the deep unroll; a lane that is done\n"
+      << "            // keeps its iterate through a zero step length instead of a branch (x + 0 * (x_raw - x) == x)\n"
+      << "            const double alphaEff = active ? " << lit(K.tran_alpha) << " : 0.0;\n"
+      << "#pragma unroll 16\n"
       << "            for (int i = 0; i < " << N << "; ++i) {\n"
-      << "                const double xo = XL(i);\n"
-      << "                const double xn = xo + " << lit(K.tran_alpha) << " * (XRL(i) - xo);\n"
-      << "                const double d = xn - xo;\n"
+      << "                const double2 pr = *reinterpret_cast<const double2*>(&XL(i));\n"
+      << "                const double xn = pr.x + alphaEff * (pr.y - pr.x);\n"
+      << "                const double d = xn - pr.x;\n"
       << "                ss += d * d;\n"
-      << "                if (active) XL(i) = xn;\n"
+      << "                XL(i) = xn;\n"
       << "            }\n"
       << "            const double err = sqrt(ss);\n"
       << "            if (active) {\n"
