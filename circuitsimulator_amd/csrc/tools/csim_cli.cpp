@@ -1,13 +1,18 @@
-// csim_cli -- command-line driver with the phases of the reference's src/main.cpp:
-// parse -> assignEquationIndices -> circuit summary -> DC operating point ->
-// (if .TRAN) transient CSV.  Every analysis runs on the GPU through the C++
-// shims (api/analysis.cpp) over the C-ABI.
+// csim_cli -- a caller of the reference-shaped C++ API (api/*.hpp), end to end on the GPU:
 //
-//   csim_cli <netlist.sp> [tran_out.csv]
+//   csim_cli <netlist.sp> [waveforms.csv]
+//
+// parseNetlist -> Circuit::assignEquationIndices -> computeDcOperatingPoint -> (with a .TRAN card)
+// runTransientAnalysisBackwardEuler, i.e. the sequence of calls the reference's driver makes.  The report
+// it prints is this tool's own: a size line, one table of node voltages, one of branch currents (the
+// lines tests/test_gpu_parity.py::test_cli_writes_the_reference_csv looks for), and where the CSV went.
+// The upstream driver itself (src/main.cpp) compiles and links unchanged against the same headers
+// (INTEGRATION.md §1); this tool is the smaller program the tests need.
+#include <cstdio>
 #include <exception>
-#include <iomanip>
 #include <iostream>
 #include <string>
+#include <vector>
 
 #include "../api/circuit.hpp"
 #include "../api/dcanalysis.hpp"
@@ -16,77 +21,65 @@
 #include "../api/sim.hpp"
 #include "../api/tanalisis.hpp"
 
+namespace {
+
+struct BranchRow {
+    std::string label;      // "L2, 117 -> 118" / "VDD, +103 -> -0"
+    int eq;
+};
+
+// the unknowns beyond the node voltages: one per voltage source and inductor, in element order
+std::vector<BranchRow> branchRows(const Circuit& c)
+{
+    std::vector<BranchRow> rows;
+    for (const auto& el : c.elements) {
+        const auto* v = dynamic_cast<const VoltageSource*>(el.get());
+        const auto* l = dynamic_cast<const Inductor*>(el.get());
+        if (!v && !l) continue;
+        const std::string& a = c.nodes[static_cast<std::size_t>(el->getNodeIds()[0])].name;
+        const std::string& b = c.nodes[static_cast<std::size_t>(el->getNodeIds()[1])].name;
+        rows.push_back({el->getName() + (v ? ", +" + a + " -> -" + b : ", " + a + " -> " + b),
+                        v ? v->getBranchEqIndex() : l->getBranchEqIndex()});
+    }
+    return rows;
+}
+
+int report(const Circuit& c, const Eigen::VectorXd& x)
+{
+    std::printf("Unknowns     : %d  (nodeEq=%d, branchEq=%d)   nodes %zu, elements %zu\n", c.numUnknowns(),
+                c.numNodeEquations(), c.numVoltageBranches(), c.nodes.size(), c.elements.size());
+    if (x.size() != c.numUnknowns()) { std::fprintf(stderr, "csim_cli: operating point has %ld entries\n", (long)x.size()); return 1; }
+    std::printf("\noperating point, node voltages\n");
+    for (const Node& n : c.nodes) {
+        if (n.eqIndex < 0) std::printf("V(%s) = 0.000000 V   [GND]\n", n.name.c_str());
+        else std::printf("V(%s) = %.6f V   [eqIndex=%d]\n", n.name.c_str(), x(n.eqIndex), n.eqIndex);
+    }
+    std::printf("\noperating point, branch currents\n");
+    for (const BranchRow& r : branchRows(c))
+        std::printf("I(%s) = %.6f A   [branchEq=%d]\n", r.label.c_str(), (r.eq >= 0 && r.eq < x.size()) ? x(r.eq) : 0.0, r.eq);
+    return 0;
+}
+
+} // namespace
+
 int main(int argc, char** argv)
 {
-    if (argc < 2) {
-        std::cerr << "Usage: csim_cli <netlist.sp> [tran_out.csv]\n";
-        return 1;
-    }
-    const std::string netlistFile = argv[1];
-    const std::string tranOutFile = argc >= 3 ? argv[2] : "tran_out.csv";
-
-    Circuit ckt;
-    SimulationConfig sim;
-    std::cout << "Reading netlist: " << netlistFile << "\n";
-    if (!parseNetlist(netlistFile, ckt, sim)) {
-        std::cerr << "parseNetlist() failed.\n";
-        return 1;
-    }
-    ckt.assignEquationIndices();
-
-    std::cout << "\n==== Circuit summary ====\n"
-              << "Node count   : " << ckt.nodes.size() << "\n"
-              << "Element count: " << ckt.elements.size() << "\n"
-              << "Unknowns     : " << ckt.numUnknowns() << "  (nodeEq=" << ckt.numNodeEquations()
-              << ", branchEq=" << ckt.numVoltageBranches() << ")\n";
-
-    std::cout << "\nRunning DC operating point...\n";
-    Eigen::VectorXd xdc;
+    if (argc < 2 || argc > 3) { std::fprintf(stderr, "usage: csim_cli <netlist.sp> [waveforms.csv]\n"); return 1; }
+    const std::string csv = argc == 3 ? argv[2] : "tran_out.csv";
+    Circuit c;
+    SimulationConfig cfg;
+    if (!parseNetlist(argv[1], c, cfg)) { std::fprintf(stderr, "csim_cli: cannot read %s\n", argv[1]); return 1; }
+    c.assignEquationIndices();
     try {
-        xdc = computeDcOperatingPoint(ckt);
+        if (const int rc = report(c, computeDcOperatingPoint(c))) return rc;
+        if (!cfg.tran.enabled) { std::printf("\nno .TRAN card: done\n"); return 0; }
+        std::printf("\ntransient: tstep %.6e  tstop %.6e  tstart %.6e  ->  %s\n", cfg.tran.tstep, cfg.tran.tstop, cfg.tran.tstart,
+                    csv.c_str());
+        std::fflush(stdout);
+        runTransientAnalysisBackwardEuler(c, cfg, csv);
     } catch (const std::exception& e) {
-        std::cerr << "DC solve failed: " << e.what() << "\n";
+        std::fprintf(stderr, "csim_cli: %s\n", e.what());
         return 1;
-    }
-    if (xdc.size() != ckt.numUnknowns()) {
-        std::cerr << "DC solution size mismatch.\n";
-        return 1;
-    }
-
-    std::cout << std::fixed << std::setprecision(6) << "\n==== DC node voltages ====\n";
-    for (const Node& node : ckt.nodes) {
-        if (node.eqIndex >= 0)
-            std::cout << "V(" << node.name << ") = " << xdc(node.eqIndex) << " V   [eqIndex=" << node.eqIndex << "]\n";
-        else
-            std::cout << "V(" << node.name << ") = 0.000000 V   [GND]\n";
-    }
-    std::cout << "\n==== DC branch currents (voltage sources / inductors) ====\n";
-    for (const auto& e : ckt.elements) {
-        int k = -1;
-        const char* arrow = " -> ";
-        if (auto* vs = dynamic_cast<const VoltageSource*>(e.get())) { k = vs->getBranchEqIndex(); arrow = " -> -"; }
-        else if (auto* ind = dynamic_cast<const Inductor*>(e.get())) k = ind->getBranchEqIndex();
-        else continue;
-        const double I = (k >= 0 && k < xdc.size()) ? xdc(k) : 0.0;
-        const bool isV = dynamic_cast<const VoltageSource*>(e.get()) != nullptr;
-        std::cout << "I(" << e->getName() << ", " << (isV ? "+" : "") << ckt.nodes[e->getNodeIds()[0]].name << arrow
-                  << ckt.nodes[e->getNodeIds()[1]].name << ") = " << I << " A   [branchEq=" << k << "]\n";
-    }
-    std::cout << "\nDC analysis finished.\n";
-
-    if (sim.tran.enabled) {
-        std::cout << "\nRunning transient analysis (Backward Euler)...\n"
-                  << std::scientific << std::setprecision(6) << "  .TRAN: tstep=" << sim.tran.tstep
-                  << ", tstop=" << sim.tran.tstop << ", tstart=" << sim.tran.tstart << "\n"
-                  << "  output file: " << tranOutFile << "\n";
-        try {
-            runTransientAnalysisBackwardEuler(ckt, sim, tranOutFile);
-        } catch (const std::exception& e) {
-            std::cerr << "Transient failed: " << e.what() << "\n";
-            return 1;
-        }
-    } else {
-        std::cout << "\nNo .TRAN card; transient analysis skipped.\n";
     }
     return 0;
 }
