@@ -222,9 +222,15 @@ int csim_engine_create(const csim_netlist* nl, int32_t device, csim_engine** out
     }
     const csim_ir* ir = nl->cir.view();
     if (ir->n_unknowns <= 0) { setError("circuit has no unknowns"); return CSIM_ERR_EMPTY; }
-    if (ir->n_unknowns > csim::bigMaxUnknowns()) {
-        setError("general kernels cover N <= 320 unknowns");
-        return CSIM_ERR_UNSUPPORTED;
+    {
+        // the reference takes any N (src/circuit.cpp:38-40); here the general kernels bound it: N <= 63 runs
+        // LDS-resident, larger circuits need their structure bit matrix, terms and three N-vectors in one
+        // CU's LDS (kernels_big.hip): N = 1024 for sparse netlists of that size, checked exactly below
+        const csim::AssemblyPlan probe = csim::buildAssemblyPlan(*ir);
+        if (ir->n_unknowns > 63 && !csim::bigSupports(ir->n_unknowns, probe.nTerms, ir->n_params)) {
+            setError("circuit too large: the general kernels need N <= 1024 and the structure in 160 KB of LDS");
+            return CSIM_ERR_UNSUPPORTED;
+        }
     }
     HIPCHK(hipSetDevice(device));
 

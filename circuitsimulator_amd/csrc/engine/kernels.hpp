@@ -34,6 +34,7 @@ hipError_t launchLuFactorDense(int n, int B, double* dLU, int32_t* dPerm, uint32
 // wave-per-instance kernels for 64 <= N <= 320 (kernels_big.hip)
 size_t bigScratchBytesPerInstance(const GenPlan& pl);
 int bigMaxUnknowns();
+bool bigSupports(int N, int nTerms, int P);
 hipError_t launchDcBig(const GenPlan& pl, const double* dParams, int B, double* dScratch, double* dX,
                        int32_t* dIters, uint32_t* dStatus, hipStream_t stream);
 hipError_t launchTranBig(const GenPlan& pl, const double* dParams, int B, double dt, long long stepFirst,

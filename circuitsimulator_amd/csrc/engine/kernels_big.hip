@@ -1,4 +1,5 @@
-// kernels_big.hip -- general kernels for circuits with 64 <= N <= 320 unknowns
+// kernels_big.hip -- general kernels for circuits with 64 <= N <= 1024 unknowns (as far as one CU's LDS
+// holds the structure: bigSupports())
 // (BASELINE config [3]: RC ladder, N = 257).
 //
 // The LDS-dense layout of kernels_general.hip needs N*(N+2)*8 bytes per instance
@@ -26,7 +27,7 @@ namespace csim {
 
 namespace {
 
-constexpr int BIG_MAX_N = 320;
+constexpr int BIG_MAX_N = 1024;          // register arrays below have one entry per 64 columns
 constexpr int BIG_CHUNKS = (BIG_MAX_N + 1 + 63) / 64;       // column chunks of 64 lanes (incl. RHS)
 
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -192,7 +193,7 @@ __device__ __forceinline__ void lu_solve_big(const GenPlan& pl, const BigLds& L,
 #pragma unroll
         for (int c = 0; c < BIG_CHUNKS; ++c) {
             const int j = c * 64 + lane;
-            ub[c] = (j > k && j <= N) && bit_of(L, rowK, j);
+            ub[c] = (c * 64 <= N) && (j > k && j <= N) && bit_of(L, rowK, j);
             u[c] = ub[c] ? Gg[rowK * LD + j] : 0.0;
         }
         // ---- eliminate every other candidate row (rows are independent of each other, so the
@@ -445,6 +446,9 @@ k_tran_big(GenPlan pl, const double* __restrict__ params, int B, double dt, long
 // ------------------------------------------------------------------ launchers
 size_t bigScratchBytesPerInstance(const GenPlan& pl) { return sizeof(double) * (size_t)pl.N * (size_t)pl.LD; }
 int bigMaxUnknowns() { return BIG_MAX_N; }
+
+// element terms, parameters, three N-vectors and the N x (N+1) bit matrix must fit one CU's LDS (160 KB)
+bool bigSupports(int N, int nTerms, int P) { return N <= BIG_MAX_N && bigLdsBytes(N, nTerms, P) <= 160 * 1024; }
 
 hipError_t launchDcBig(const GenPlan& pl, const double* dParams, int B, double* dScratch, double* dX,
                        int32_t* dIters, uint32_t* dStatus, hipStream_t stream)

@@ -747,6 +747,41 @@ def test_rc_ladder_large_n_general_kernels(ladder, torch_mod):
         assert np.abs(r["wave"][:, :, b] - ref).max() <= TOL * max(np.abs(ref).max(), 1e-6)
 
 
+def test_circuit_beyond_320_unknowns(torch_mod, tmp_path, monkeypatch):
+    """The reference takes any N (src/circuit.cpp:38-40).  A 600-node RC ladder (601 unknowns) through the
+    large-N general kernels (structure bit matrix in LDS, values in global memory) and through the generated
+    linear-circuit kernel (16 instances per workgroup at this size), against the oracle; and the size at
+    which the engine does refuse."""
+    from circuitsimulator_amd import CsimError, Engine, Netlist
+    from circuitsimulator_amd.workloads import rc_ladder_netlist
+    monkeypatch.setenv("CSIM_JIT_DIR", str(tmp_path / "jit"))
+    nl = Netlist.from_text(rc_ladder_netlist(600))
+    N = nl.n_unknowns
+    assert N == 601
+    eng = Engine(nl, 0)
+    B, steps = 20, 3
+    params = eng.mc_params(5, 0.05, 0, B)
+    slow = _run_tran(torch_mod, eng, params[:, :2].contiguous(), steps, nl.tstep, want_step_iters=True)
+    ph = params.cpu().numpy()
+    o = _orc().tran(nl.ir_ptr, N, ph, 1, nl.tstep, nl.tstep * steps, want_rows=False, want_step_iters=True)
+    assert np.array_equal(slow["step_iters"][:, 1], o["step_iters"]) and slow["status"][1] == o["status"]
+    assert rel_err(slow["x"][:, 1], o["x_final"]).max() < TOL
+    xo, ito, _ = _orc().dc(nl.ir_ptr, N, ph, 1)
+    assert slow["dc_iters"][1] == ito == 1 and rel_err(slow["x_dc"][:, 1], xo).max() < TOL
+    eng.jit_scheduled(params, plan_steps=2)
+    assert eng.tran_kernel == "scheduled"
+    fast = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+    assert not (fast["status"] & 0x27).any()
+    assert np.array_equal(fast["step_iters"][:, :2], slow["step_iters"])
+    assert rel_err(fast["x"][:, :2].T, slow["x"].T).max() < TOL
+    o = _orc().tran(nl.ir_ptr, N, ph, B - 1, nl.tstep, nl.tstep * steps, want_rows=False, want_step_iters=True)
+    assert np.array_equal(fast["step_iters"][:, B - 1], o["step_iters"])
+    assert rel_err(fast["x"][:, B - 1], o["x_final"]).max() < TOL
+    with pytest.raises(CsimError) as e:                     # 1025 unknowns: beyond the large-N kernels
+        Engine(Netlist.from_text(rc_ladder_netlist(1024)), 0)
+    assert e.value.code == -5
+
+
 def test_rc_ladder_full_waveform_host_api(ladder):
     """All 257 unknowns probed (more probes than lanes) through the instance-major host API."""
     nl, eng = ladder
