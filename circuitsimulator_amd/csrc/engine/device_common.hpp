@@ -187,9 +187,9 @@ __device__ __forceinline__ MosLin mos_eval(bool isP, double Vth, double K, doubl
 
 // ---- terms that stay constant over a launch
 template <bool TRAN>
-__device__ __forceinline__ void terms_const(const GenPlan& pl, const double* Pv, double* T, double dt, int lane)
+__device__ __forceinline__ void terms_const(const GenPlan& pl, const double* Pv, double* T, double dt, int lane, int stride = 64)
 {
-    for (int e = lane; e < pl.nElem; e += 64) {
+    for (int e = lane; e < pl.nElem; e += stride) {
         const int kind = pl.kind[e], s = pl.slot[e], tb = pl.termBase[e];
         if (kind == CSIM_R) {
             const double R = Pv[s];
@@ -216,9 +216,9 @@ __device__ __forceinline__ void terms_const(const GenPlan& pl, const double* Pv,
 
 // ---- terms that change once per time step: sources and history currents
 __device__ __forceinline__ void terms_step_tran(const GenPlan& pl, const double* Pv, double* T,
-                                                const double* xp, double t, int lane)
+                                                const double* xp, double t, int lane, int stride = 64)
 {
-    for (int e = lane; e < pl.nElem; e += 64) {
+    for (int e = lane; e < pl.nElem; e += stride) {
         const int kind = pl.kind[e], s = pl.slot[e], tb = pl.termBase[e];
         const int32_t* q = pl.eq + 4 * e;
         if (kind == CSIM_V || kind == CSIM_I) {
@@ -242,9 +242,9 @@ __device__ __forceinline__ void terms_step_tran(const GenPlan& pl, const double*
     }
 }
 
-__device__ __forceinline__ void terms_step_dc(const GenPlan& pl, const double* Pv, double* T, double scale, int lane)
+__device__ __forceinline__ void terms_step_dc(const GenPlan& pl, const double* Pv, double* T, double scale, int lane, int stride = 64)
 {
-    for (int e = lane; e < pl.nElem; e += 64) {
+    for (int e = lane; e < pl.nElem; e += stride) {
         const int kind = pl.kind[e];
         if (kind == CSIM_V || kind == CSIM_I)
             T[pl.termBase[e] + T_SRC_VAL] = source_value_dc(Pv, pl.slot[e], pl.wave[e], scale);
@@ -252,9 +252,9 @@ __device__ __forceinline__ void terms_step_dc(const GenPlan& pl, const double* P
 }
 
 // ---- terms that change every Newton iteration: MOS channel at the iterate x
-__device__ __forceinline__ void terms_iter_mos(const GenPlan& pl, const double* Pv, double* T, const double* x, int lane)
+__device__ __forceinline__ void terms_iter_mos(const GenPlan& pl, const double* Pv, double* T, const double* x, int lane, int stride = 64)
 {
-    for (int e = lane; e < pl.nElem; e += 64) {
+    for (int e = lane; e < pl.nElem; e += stride) {
         const int kind = pl.kind[e];
         if (kind != CSIM_NMOS && kind != CSIM_PMOS) continue;
         const int s = pl.slot[e], tb = pl.termBase[e];
@@ -270,12 +270,12 @@ __device__ __forceinline__ void terms_iter_mos(const GenPlan& pl, const double* 
 
 // ---- build [G | I] in LDS: clear, then every structural non-zero sums its
 // terms in the reference's accumulation order
-__device__ __forceinline__ void assemble(const GenPlan& pl, const double* T, double* Gm, int lane)
+__device__ __forceinline__ void assemble(const GenPlan& pl, const double* T, double* Gm, int lane, int stride = 64)
 {
     const int total = pl.N * pl.LD;
-    for (int i = lane; i < total; i += 64) Gm[i] = 0.0;
+    for (int i = lane; i < total; i += stride) Gm[i] = 0.0;
     wave_sync();
-    for (int n = lane; n < pl.nnzG; n += 64) {
+    for (int n = lane; n < pl.nnzG; n += stride) {
         double acc = 0.0;
         for (int c = pl.gPtr[n]; c < pl.gPtr[n + 1]; ++c) {
             const int con = pl.gCon[c];
@@ -284,7 +284,7 @@ __device__ __forceinline__ void assemble(const GenPlan& pl, const double* T, dou
         }
         Gm[pl.gPos[n]] = acc;
     }
-    for (int n = lane; n < pl.nnzI; n += 64) {
+    for (int n = lane; n < pl.nnzI; n += stride) {
         double acc = 0.0;
         for (int c = pl.iPtr[n]; c < pl.iPtr[n + 1]; ++c) {
             const int con = pl.iCon[c];

@@ -25,6 +25,16 @@ hipError_t launchLuFactor(int n, int B, const double* dA, double* dLU, int32_t* 
                           double eps, hipStream_t stream);
 size_t generalLdsBytes(const GenPlan& pl);
 
+// the same kernels with 2 (N <= 31) or 4 (N <= 15) instances per wavefront (kernels_packed.hip); the
+// launchers above use them whenever no pivot log is asked for
+int packedLanesFor(int N);
+hipError_t launchDcPacked(const GenPlan& pl, const double* dParams, int B, double* dX, int32_t* dIters,
+                          uint32_t* dStatus, hipStream_t stream, const uint8_t* dOnly);
+hipError_t launchTranPacked(const GenPlan& pl, const double* dParams, int B, double dt, long long stepFirst,
+                            long long nSteps, const int32_t* dProbeEq, int nProbe, int outStride, double* dWave,
+                            double* dX, long long* dIters, uint32_t* dStatus, int32_t* dStepIters, const uint8_t* dOnly,
+                            hipStream_t stream, int32_t* dDone, int maxSteps, const int32_t* dKnownAlts, int nKnown);
+
 // dense stand-alone LU for 64 <= n <= 1024, one workgroup per system, in place (kernels_dense.hip)
 hipError_t launchLuSolveDense(int n, int B, double* dWork, const double* dRhs, double* dX, uint32_t* dFlags,
                               double eps, hipStream_t stream);
