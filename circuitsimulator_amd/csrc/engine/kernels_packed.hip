@@ -1,5 +1,5 @@
-// kernels_packed.hip -- the general (dynamic-pivot, bit-faithful) kernels with SEVERAL instances per
-// wavefront, for small circuits:  G = 32 lanes per instance (N <= 31: 2 per wave) and G = 16 (N <= 15: 4).
+// kernels_packed.hip -- the general (dynamic-pivot, bit-faithful) kernels with FOUR instances per
+// wavefront (G = 16 lanes per instance) for circuits with N <= 15 unknowns (tests/buffer.sp: N = 13).
 //
 // kernels_general.hip gives a whole wavefront to one instance.  Its round-1 profile shows it is
 // issue-bound, not latency-bound: ~4 500 vector + ~4 200 scalar instructions per NR iteration at N = 31,
@@ -18,6 +18,13 @@
 //     stepping), converge after different numbers of passes, or stop -- each of those is a per-group flag,
 //     never a branch around a barrier.
 // The planner (pivot log) stays on the one-instance-per-wave kernels.
+//
+// Measured (MI355X, B = 4096): buffer.sp DC operating points 20.1 ms -> 8.8 ms with G = 16.  The same
+// code with G = 32 (two instances per wave, N <= 31) was measured on dbmixer.sp and is NOT used: 6.0e7
+// NR-iter*inst/s with ds_bpermute broadcasts and 4.9e7 with pairs of v_readlane + select, against 6.7e7
+// for one instance per wave -- at two per wave the vector forms of the walks (per-lane ffs, masks,
+// predicates) cost about what the second instance saves, and the doubled LDS footprint halves the waves
+// that hide the rest.
 #include <hip/hip_runtime.h>
 
 #include "device_common.hpp"
@@ -29,6 +36,7 @@ namespace csim {
 
 namespace {
 
+// value of sub-lane `sub` of each group (sub is uniform within a group, may differ between groups)
 template <int G> __device__ __forceinline__ double grp_get(double v, int sub, int q) { return __shfl(v, q * G + sub); }
 template <int G> __device__ __forceinline__ unsigned grp_mask(bool pred, int q)
 {
@@ -359,7 +367,7 @@ k_tran_packed(GenPlan pl, const double* __restrict__ params, int B, double dt,
 }
 
 // ------------------------------------------------------------------ launchers
-int packedLanesFor(int N) { return N <= 15 ? 16 : (N <= 31 ? 32 : 64); }
+int packedLanesFor(int N) { return N <= 15 ? 16 : 64; }
 
 hipError_t launchDcPacked(const GenPlan& pl, const double* dParams, int B, double* dX, int32_t* dIters,
                           uint32_t* dStatus, hipStream_t stream, const uint8_t* dOnly)
@@ -368,8 +376,8 @@ hipError_t launchDcPacked(const GenPlan& pl, const double* dParams, int B, doubl
     const LdsLayout L = ldsLayout(pl.N, pl.LD, pl.nTerms, pl.P);
     const size_t lds = sizeof(double) * (size_t)(L.total + 1) * ipw;
     const dim3 grid((B + ipw - 1) / ipw);
-    if (G == 16) hipLaunchKernelGGL(k_dc_packed<16>, grid, dim3(64), lds, stream, pl, dParams, B, dX, dIters, dStatus, dOnly);
-    else hipLaunchKernelGGL(k_dc_packed<32>, grid, dim3(64), lds, stream, pl, dParams, B, dX, dIters, dStatus, dOnly);
+    if (G != 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_dc_packed<16>, grid, dim3(64), lds, stream, pl, dParams, B, dX, dIters, dStatus, dOnly);
     return hipGetLastError();
 }
 
@@ -382,12 +390,9 @@ hipError_t launchTranPacked(const GenPlan& pl, const double* dParams, int B, dou
     const LdsLayout L = ldsLayout(pl.N, pl.LD, pl.nTerms, pl.P);
     const size_t lds = sizeof(double) * (size_t)(L.total + 1) * ipw;
     const dim3 grid((B + ipw - 1) / ipw);
-    if (G == 16)
-        hipLaunchKernelGGL(k_tran_packed<16>, grid, dim3(64), lds, stream, pl, dParams, B, dt, stepFirst, nSteps, dProbeEq,
-                           nProbe, outStride, dWave, dX, dIters, dStatus, dStepIters, dOnly, dDone, maxSteps, dKnownAlts, nKnown);
-    else
-        hipLaunchKernelGGL(k_tran_packed<32>, grid, dim3(64), lds, stream, pl, dParams, B, dt, stepFirst, nSteps, dProbeEq,
-                           nProbe, outStride, dWave, dX, dIters, dStatus, dStepIters, dOnly, dDone, maxSteps, dKnownAlts, nKnown);
+    if (G != 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_tran_packed<16>, grid, dim3(64), lds, stream, pl, dParams, B, dt, stepFirst, nSteps, dProbeEq,
+                       nProbe, outStride, dWave, dX, dIters, dStatus, dStepIters, dOnly, dDone, maxSteps, dKnownAlts, nKnown);
     return hipGetLastError();
 }
 

@@ -423,7 +423,7 @@ def test_error_codes(engines):
     with pytest.raises(CsimError) as e:
         Engine(nl, 99)
     assert e.value.code == capi.CSIM_ERR_NO_DEVICE
-    big = "V1 n0 0 1\n" + "".join("R%d n%d n%d 1\n" % (i, i, i + 1) for i in range(330)) + "R999 n330 0 1\n"
+    big = "V1 n0 0 1\n" + "".join("R%d n%d n%d 1\n" % (i, i, i + 1) for i in range(1030)) + "R9999 n1030 0 1\n"
     with pytest.raises(CsimError) as e:
         Engine(Netlist.from_text(big), 0)
     assert e.value.code == capi.CSIM_ERR_UNSUPPORTED

@@ -18,10 +18,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, nargs="+", default=[4096, 131072])
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--netlist", default="dbmixer.sp", help="file under tests/golden/")
     a = ap.parse_args()
     import torch
     from circuitsimulator_amd import Engine, Netlist
-    nl = Netlist.from_file(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "dbmixer.sp"))
+    nl = Netlist.from_file(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", a.netlist))
     eng = Engine(nl, 0)
     for B in a.batch:
         params = eng.mc_params(12345, 0.05, 0, B)
