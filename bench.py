@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--no-jit", action="store_true", help="do not JIT-specialise a netlist without a prebuilt kernel")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--sigma", type=float, default=0.05)
-    ap.add_argument("--kernel", default="auto", choices=["auto", "general", "scheduled"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "general", "scheduled", "faithful"])
     ap.add_argument("--cpu-iters", type=float, default=3.0e6, help="approx. NR iterations of the CPU sample (~15 s)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the all-cores CPU leg (1 = skip it)")
@@ -263,8 +263,9 @@ def main():
         abytes = algorithmic_bytes_per_iter(N)
         achieved = iters_per_launch * abytes / avg_kern_s / 1e9
         kernel = eng.tran_kernel
-        lanes = eng.lanes_for_batch(B) if kernel == "scheduled" else 64
+        lanes = eng.lanes_for_batch(B) if kernel == "scheduled" else (1 if kernel == "faithful" else 64)
         ckey = kernel if lanes in (1, 64) else "%s%d" % (kernel, lanes)
+        flagged_mask = 0xA7
         counters = profiled_counters(nl, ckey, B)
         flops_exec = executed_flops_per_unit(eng, nl) if kernel == "scheduled" else None
         frac = achieved / HBM_PEAK_GBS

@@ -28,6 +28,7 @@ ST_DC_NONCONV = 0x0008
 ST_DC_NONFINITE = 0x0010
 ST_SCHED_FALLBACK = 0x0020
 ST_SCHED_FALLBACK_DC = 0x0080
+ST_SCHED_FAITHFUL = 0x0100
 ST_LU_ZERO_DIAG = 0x0040
 
 # every symbol include/csim.h declares: name -> (restype, argtypes)

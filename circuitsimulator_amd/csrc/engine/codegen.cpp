@@ -232,6 +232,20 @@ struct Gen {
         r.neg = a.neg != b.neg;
         return r;
     }
+    // a / b (faithful kernels: solver.hpp:71 and :126 divide)
+    AV div(const AV& a, const AV& b)
+    {
+        if (a.isZero()) return AV::zero();
+        if (a.kind == AV::CONST && b.kind == AV::CONST) return AV::konst(a.c / b.c);
+        if (b.kind == AV::CONST) {
+            if (b.c == 1.0) return a;
+            if (b.c == -1.0) return negate(a);
+            return emit(ref(a) + " / " + lit(b.c));
+        }
+        AV r = emit((a.kind == AV::CONST ? lit(a.c) : a.v) + " / " + b.v);
+        r.neg = (a.kind == AV::DYN && a.neg) != b.neg;
+        return r;
+    }
     // a - f*u
     AV fnma(const AV& a, const AV& f, const AV& u)
     {
@@ -311,6 +325,10 @@ struct VariantOptions {
     int ckUnroll = 4;   // unroll factor of the per-step checkpoint loop (swept 1/2/4/8/31: 4 best, 31 pins 2N VGPRs)
     bool dcMode = false;// emit the DC operating-point kernel (source ramp + ConvController) instead of the transient
     int wavesPerEu = 0; // > 0: amdgpu_waves_per_eu(n, n) -- caps registers at 512 / n per lane (tuning aid)
+    // the reference's arithmetic: no FMA contraction, one true division per multiplier and per solution entry
+    // instead of a reciprocal, and no slow-step rule (a step that ends at the NR cap is kept and flagged as
+    // upstream): on a recorded pivot sequence this kernel is bit-faithful, like the general kernels
+    bool faithful = false;
 };
 
 // emits ONE __global__ kernel; returns the number of LDS doubles per lane it uses
@@ -426,6 +444,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             << "    const long long SB = B;\n"
             << "    const bool splitFlag = B < 0;              // never true; opaque to the compiler\n";
     } else {
+        if (opt.faithful) src << "#pragma clang fp contract(off)\n";
         src << "extern \"C\" __global__ void __launch_bounds__(64)"
             << (opt.wavesPerEu > 0 ? " __attribute__((amdgpu_waves_per_eu(" + std::to_string(opt.wavesPerEu) + ", " + std::to_string(opt.wavesPerEu) + ")))" : std::string()) << "\n"
             << opt.kernelName << "(const double* __restrict__ params, int B, double dt, long long stepFirst,\n"
@@ -739,15 +758,16 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
                 std::swap(g.pending[static_cast<std::size_t>(p)], g.pending[static_cast<std::size_t>(k)]);
             }
             const AV piv = at(k, k);
-            AV r;
-            if (piv.kind == AV::CONST) r = AV::konst(1.0 / piv.c);
+            AV r;                       // what the row is scaled with: 1 / pivot, or (faithful) the pivot itself as divisor
+            if (opt.faithful) r = piv;
+            else if (piv.kind == AV::CONST) r = AV::konst(1.0 / piv.c);
             else if (piv.kind == AV::DYN) { r = g.emit("rcp_nr(" + g.ref(piv) + ")"); ++g.st.nRecip; }
             rinv[static_cast<std::size_t>(k)] = r;
             for (int i = k + 1; i < N; ++i) {
                 const AV aik = at(i, k);
                 if (aik.isZero()) continue;
                 ++g.st.nLower;
-                const AV f = g.mul(aik, r);                                  // multiplier (solver.hpp:71)
+                const AV f = opt.faithful ? g.div(aik, r) : g.mul(aik, r);     // multiplier (solver.hpp:71)
                 for (int j = k + 1; j <= N; ++j) {
                     if (M[static_cast<std::size_t>(k)][static_cast<std::size_t>(j)].isZero()) continue;
                     const AV u = at(k, j);
@@ -792,7 +812,8 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
                 if (u.kind == AV::DYN) ++g.st.nDynU;
                 sum = g.fnma(sum, u, xr[static_cast<std::size_t>(j)]);
             }
-            xr[static_cast<std::size_t>(i)] = g.mul(sum, rinv[static_cast<std::size_t>(i)]);
+            xr[static_cast<std::size_t>(i)] = opt.faithful ? g.div(sum, rinv[static_cast<std::size_t>(i)])      // :126
+                                                           : g.mul(sum, rinv[static_cast<std::size_t>(i)]);
         }
 
 
@@ -895,8 +916,10 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         // in the state -- so such a step is treated like a failed pivot check: the lane stops at the step's
         // checkpoint and the bit-faithful general kernel redoes it (and sets CSIM_ST_TRAN_NONCONV if due).
         const int slowIters = slowStepIters(K.tran_tol, K.tran_alpha, K.tran_max_iters);
-        o << g.ind << "        if (err < " << lit(K.tran_tol) << ") active = false;\n"
-          << g.ind << "        else if (iter >= " << (slowIters - 1) << ") { viol = true; active = false; }\n"
+        o << g.ind << "        if (err < " << lit(K.tran_tol) << ") active = false;\n";
+        if (opt.faithful) o << g.ind << "        else if (iter == " << (K.tran_max_iters - 1) << ") st |= ST_TRAN_NONCONV;   // tanalisis.cpp:372-376\n";
+        else o << g.ind << "        else if (iter >= " << (slowIters - 1) << ") { viol = true; active = false; }\n";
+        o
           << g.ind << "    }\n"
           << g.ind << "}\n";
 
@@ -909,6 +932,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             << i2 << "        const long long row = gstep / outStride;\n"
             << i2 << "        for (int q = 0; q < nProbe; ++q) wave[(row * nProbe + q) * SB + b] = X(probeEq[q]);\n"
             << i2 << "    }\n"
+            << (opt.faithful ? i2 + "    st |= ST_SCHED_FAITHFUL;\n" : std::string())
             << i2 << "    sdone = dead ? nSteps : s;\n"
             << i2 << "}\n"
             << "    }\n\n"
@@ -922,7 +946,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             << "        status[b] |= st;\n"
             << "        done[b] = (int)sdone;\n"
             << "    }\n"
-            << "}\n\n";
+            << "}\n" << (opt.faithful ? "#pragma clang fp contract(fast)\n" : "") << "\n";
 
     }
 
@@ -949,7 +973,7 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "//   csim_tran_sched_kernel_rich  every finished U-row value parked in LDS (tuning aid: measured\n"
         << "//                                slower -- ds traffic costs more than the spills it removes)\n"
         << "#include <hip/hip_runtime.h>\n#include <stdint.h>\n\n"
-        << "#define ST_TRAN_NONFINITE 0x0001u\n#define ST_TRAN_NONCONV 0x0002u\n#define ST_DC_NONCONV 0x0008u\n\n"
+        << "#define ST_TRAN_NONFINITE 0x0001u\n#define ST_TRAN_NONCONV 0x0002u\n#define ST_DC_NONCONV 0x0008u\n#define ST_SCHED_FAITHFUL 0x0100u\n\n"
         << "#define Q(k) lds[(k) * 64 + lane]\n#define X(i) Q(i)\n#define S(j) Q(" << N << " + (j))\n\n"
         << "// Newton-refined reciprocal (v_rcp_f64 + 2 FMA pairs, ~1 ulp) for the pivots\n"
         << "__device__ __forceinline__ double clamp01_cg(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }\n"
@@ -989,6 +1013,14 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     // rich: same residency, every finished U row parked (more LDS per wave: fewer waves per CU)
     const int ldsRich = haveLinear ? -1 : emitVariant({"csim_tran_sched_kernel_rich", false, false, -1}, nullptr);
     const bool haveRich = ldsRich >= 0;
+    // faithful: the reference's arithmetic on the recorded pivot sequences (what slow steps are redone with)
+    int ldsFaith = -1;
+    if (!haveLinear) {
+        VariantOptions fo{"csim_tran_faithful_kernel", false, false, leanBudget > 0 ? leanBudget : 0};
+        fo.faithful = true;
+        ldsFaith = emitVariant(fo, nullptr);
+    }
+    const bool haveFaithful = ldsFaith >= 0;
     const std::vector<int>& sweep = gopt.sweep;      // tuning aid (csim_codegen --sweep): extra kernels
     {
         for (std::size_t k = 0; k < sweep.size(); ++k) {
@@ -1040,6 +1072,8 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "// doubles per instance of the work area csim_sched_launch needs (0: none): the linear-circuit kernel parks\n"
         << "// its factors there\n"
         << "extern \"C\" int csim_sched_work_doubles(void) { return " << (haveLinear ? linWork : 0) << "; }\n"
+        << "// 1 when this library carries csim_tran_faithful_kernel (csim_sched_launch variant 3)\n"
+        << "extern \"C\" int csim_sched_has_faithful(void) { return " << (haveFaithful ? 1 : 0) << "; }\n"
         << "// 16 when this library also carries csim_tran_group_kernel (sixteen lanes per instance, first schedule only)\n"
         << "extern \"C\" int csim_sched_group_lanes(void) { return " << (haveGroup ? 16 : 0) << "; }\n";
     src << ""
@@ -1083,6 +1117,12 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
             << "        hipLaunchKernelGGL(csim_tran_linear_kernel, dim3((unsigned)((B + " << linLanes - 1 << ") / " << linLanes << ")), dim3(" << linLanes << "), 0, (hipStream_t)stream,\n"
             << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
             << "                           stepIters, fallback, done, violFlag, work);\n"
+            << "        return (int)hipGetLastError();\n    }\n";
+    if (haveFaithful)
+        src << "    if (variant == 3) {\n"
+            << "        hipLaunchKernelGGL(csim_tran_faithful_kernel, dim3(waves), dim3(64), 0, (hipStream_t)stream,\n"
+            << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
+            << "                           stepIters, fallback, done, violFlag);\n"
             << "        return (int)hipGetLastError();\n    }\n";
     if (haveGroup)
         src << "    if (variant == 16) {\n"

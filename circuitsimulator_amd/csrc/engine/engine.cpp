@@ -141,6 +141,8 @@ void adoptScheduleTable(csim_engine* eng, void* lib)
     typedef int (*LanesFn)(void);
     LanesFn lanesFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_group_lanes"));
     eng->schedGroupLanes = lanesFn ? lanesFn() : 0;
+    LanesFn faithFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_has_faithful"));
+    eng->schedHasFaithful = faithFn && faithFn() != 0;
     LanesFn workFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_work_doubles"));
     eng->schedWorkDoubles = workFn ? workFn() : 0;
     // DC operating-point kernel, present when the library was generated with "dc" schedules
@@ -284,7 +286,8 @@ void csim_engine_destroy(csim_engine* eng)
 const char* csim_engine_tran_kernel(const csim_engine* eng)
 {
     if (!eng) return "";
-    return (eng->schedLaunch && eng->kernelChoice != 1) ? "scheduled" : "general";
+    if (!(eng->schedLaunch && eng->kernelChoice != 1)) return "general";
+    return (eng->kernelChoice == 3 && eng->schedHasFaithful) ? "faithful" : "scheduled";
 }
 
 const char* csim_engine_sched_info(const csim_engine* eng)
@@ -294,7 +297,11 @@ const char* csim_engine_sched_info(const csim_engine* eng)
 
 int csim_engine_set_kernel(csim_engine* eng, int32_t which)
 {
-    if (!eng || which < 0 || which > 2) return CSIM_ERR_ARG;
+    if (!eng || which < 0 || which > 3) return CSIM_ERR_ARG;
+    if (which == 3 && !(eng->schedLaunch && eng->schedHasFaithful)) {
+        setError("no faithful scheduled kernel is available for this circuit");
+        return CSIM_ERR_UNSUPPORTED;
+    }
     if (which == 2 && !eng->schedLaunch) {
         setError("no scheduled kernel is available for this circuit (libcsim_sched_<topology>.so not found)");
         return CSIM_ERR_UNSUPPORTED;
@@ -484,21 +491,31 @@ int csim_tran_batch_dev(csim_engine* eng, const double* d_params, int32_t B, dou
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dSchedWork), sizeof(double) * (size_t)eng->schedWorkDoubles * ((size_t)B + 64)));   // whole workgroups
         eng->schedWorkCap = B;
     }
-    auto scheduled = [&](bool* anyUnfinished) -> int {
+    auto scheduled = [&](int variant, bool* anyUnfinished) -> int {
         HIPCHK(hipMemsetAsync(eng->dViolFlag, 0, sizeof(int32_t), hs));
         const int lrc = eng->schedLaunch(d_params, B, tstep, step_first, n_steps, dProbe, np, os, d_wave, d_x,
                                          reinterpret_cast<long long*>(d_iters), d_status, d_step_iters,
-                                         eng->dFallback, eng->dDone, eng->dViolFlag, eng->dSchedWork, stream,
-                                         schedVariantFor(eng, B));
+                                         eng->dFallback, eng->dDone, eng->dViolFlag, eng->dSchedWork, stream, variant);
         if (lrc != 0) { setError(std::string("scheduled kernel launch: ") + hipGetErrorString((hipError_t)lrc)); return CSIM_ERR_HIP; }
         return readViolFlag(eng, hs, anyUnfinished);
     };
+    // Kernel ladder for an instance that leaves the fast kernel: (1) the FAITHFUL generated kernel -- same
+    // recorded pivot sequences, the reference's arithmetic (true divisions, no contraction, no slow-step
+    // rule), so slow / non-convergent steps are redone there bit-faithfully at lane-per-instance speed; it
+    // stops an instance only when no recorded sequence fits; (2) the general kernel with run-time pivoting,
+    // which hands the instance back once a whole step ran on recorded sequences again.
+    const bool faithfulOnly = eng->kernelChoice == 3 && eng->schedHasFaithful;
+    const int fast = faithfulOnly ? 3 : schedVariantFor(eng, B);
     bool unfinished = false;
-    int rc = scheduled(&unfinished);
+    int rc = scheduled(fast, &unfinished);
     if (rc || !unfinished) return rc;
-    for (int r = 0; r < eng->cfg.hybridRounds; ++r) {
+    for (int r = 0; r <= eng->cfg.hybridRounds; ++r) {
+        if (eng->schedHasFaithful && !faithfulOnly) {
+            if ((rc = scheduled(3, &unfinished)) || !unfinished) return rc;
+        }
+        if (r == eng->cfg.hybridRounds) break;
         if ((rc = general(eng->dDone, eng->cfg.hybridSteps, true))) return rc;
-        if ((rc = scheduled(&unfinished)) || !unfinished) return rc;
+        if ((rc = scheduled(fast, &unfinished)) || !unfinished) return rc;
     }
     return general(eng->dDone, 2147483647);      // whatever is still unfinished runs to the end of the launch
 }

@@ -26,7 +26,7 @@ struct EngineConfig {
 
 struct csim_engine {
     int device = 0;
-    int kernelChoice = 0;                  // 0 auto, 1 general, 2 scheduled
+    int kernelChoice = 0;                  // 0 auto, 1 general, 2 scheduled, 3 scheduled with the reference's arithmetic
     EngineConfig cfg;
     csim::CircuitIR cir;                   // private copy of the flattened circuit
     csim::AssemblyPlan plan;
@@ -54,6 +54,7 @@ struct csim_engine {
     int schedWorkDoubles = 0;              // per-instance doubles of the work area the library's launcher wants
     double* dSchedWork = nullptr;
     int schedWorkCap = 0;                  // instances
+    bool schedHasFaithful = false;         // the library carries csim_tran_faithful_kernel (launch variant 3)
     int schedGroupLanes = 0;               // 16 when the library also carries the sixteen-lanes-per-instance kernel
     int32_t* dKnownAlts = nullptr;         // [nKnownAlts][N] pivot sequences the loaded kernel carries
     int nKnownAlts = 0;

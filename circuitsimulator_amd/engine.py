@@ -157,7 +157,7 @@ class Engine:
         return n if n else 64
 
     def set_kernel(self, which):
-        capi.check(capi.lib().csim_engine_set_kernel(self._h, {"auto": 0, "general": 1, "scheduled": 2}[which]))
+        capi.check(capi.lib().csim_engine_set_kernel(self._h, {"auto": 0, "general": 1, "scheduled": 2, "faithful": 3}[which]))
 
     def set_option(self, key, value):
         """csim_engine_set_option: hybrid_rounds, hybrid_steps, lanes_per_instance, jit_dir, ... (include/csim.h)"""

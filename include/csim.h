@@ -106,8 +106,8 @@ int  csim_netlist_mc_kinds(const csim_netlist* nl, int32_t* kinds);
 int  csim_engine_create(const csim_netlist* nl, int32_t device, csim_engine** out);
 void csim_engine_destroy(csim_engine* eng);
 /* which transient kernel the engine will use: "general" (wave-per-instance,
- * dense LDS LU with dynamic pivoting) or "scheduled" (lane-per-instance,
- * circuit-specialised code with a verified pivot schedule)                   */
+ * dense LDS LU with dynamic pivoting), "scheduled" (circuit-specialised code with
+ * a verified pivot schedule) or "faithful" (the same with the reference's arithmetic) */
 const char* csim_engine_tran_kernel(const csim_engine* eng);
 /* description of the loaded generated library ("" if none): circuit, pivot schedules, LDS doubles
  * per lane, and the floating-point operations ONE solve on the first schedule executes
@@ -116,7 +116,9 @@ const char* csim_engine_sched_info(const csim_engine* eng);
 /* lanes per instance the scheduled transient kernel would use for a batch of B instances (1 or 16;
  * 0 = the general kernel runs: one 64-lane wavefront per instance)                              */
 int  csim_engine_lanes_for_batch(const csim_engine* eng, int32_t B);
-/* force a kernel family: 0 = auto, 1 = general only, 2 = scheduled required  */
+/* force a kernel family: 0 = auto, 1 = general only, 2 = scheduled required, 3 = the generated kernel
+ * with the reference's arithmetic ("faithful": true divisions, no FMA contraction, steps at the NR cap
+ * kept and flagged; bit-faithful on recorded pivot sequences, run-time pivoting kernel for the rest)    */
 int  csim_engine_set_kernel(csim_engine* eng, int32_t which);
 
 /* Run-time options of one engine, as text.  The environment variable named with each key is read

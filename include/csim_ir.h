@@ -152,6 +152,7 @@ static inline void csim_consts_default(csim_consts* k)
 #define CSIM_ST_SCHED_FALLBACK   0x0020u  /* pre-recorded pivot schedule violated -> instance re-run dense */
 #define CSIM_ST_LU_ZERO_DIAG     0x0040u  /* back-substitution met |diag|<eps -> x(i)=0 (solver.hpp:122)  */
 
+#define CSIM_ST_SCHED_FAITHFUL   0x0100u  /* >=1 time step ran on the generated kernel with the reference's arithmetic (informational) */
 #define CSIM_ST_SCHED_FALLBACK_DC 0x0080u /* same, for the DC operating point (informational: results are the general kernel's) */
 
 #ifdef __cplusplus

@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-9
 FALLBACK = 0x20          # CSIM_ST_SCHED_FALLBACK: informational (instance was re-run by the general kernel)
 FALLBACK_DC = 0x80       # CSIM_ST_SCHED_FALLBACK_DC: the same for the DC operating point
-NOFB = 0xFFFFFF5F        # mask that drops both
+FAITHFUL = 0x100         # CSIM_ST_SCHED_FAITHFUL: informational (>= 1 step ran on the faithful generated kernel)
+NOFB = 0xFFFFFE5F        # mask that drops the three informational bits
 
 
 @pytest.fixture(scope="module")
@@ -194,6 +195,35 @@ def test_dbmixer_full_run_monte_carlo_instances(engines, torch_mod):
         o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstop, want_rows=False)
         assert o["n_steps"] == 50000 and its[b] == o["iters"], (b, its[b], o["iters"])
         assert rel_err(xs[:, b], o["x_final"]).max() < TOL
+
+
+# --------------------------------------- the generated kernel with the reference's arithmetic
+
+def test_faithful_generated_kernel_is_bitwise_the_general_kernel(engines, torch_mod):
+    """set_kernel("faithful"): the lane-per-instance generated kernel emitted with true divisions, without
+    FMA contraction and without the slow-step rule.  On recorded pivot sequences it performs the reference's
+    operations in the reference's order, so it must reproduce the general kernel (itself bit-identical to the
+    oracle's LU) BIT FOR BIT -- state, NR counts, status -- on dbmixer and, through its alternatives and the
+    hand-over for what they do not cover, on the switching buffer."""
+    for name, B, steps in (("dbmixer", 96, 300), ("buffer", 64, 200)):
+        nl, eng = engines[name]
+        params = eng.mc_params(321, 0.05, 0, B)
+        eng.set_kernel("general")
+        slow = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True, probes=[0, 1], stride=7)
+        eng.set_kernel("faithful")
+        assert eng.tran_kernel == "faithful"
+        try:
+            fast = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True, probes=[0, 1], stride=7,
+                             chunks=[steps // 3, steps - steps // 3])
+        finally:
+            eng.set_kernel("auto")
+        assert np.array_equal(fast["step_iters"], slow["step_iters"]), name
+        assert np.array_equal(fast["status"] & NOFB, slow["status"]), name
+        assert np.array_equal(fast["x"], slow["x"]), name                      # bitwise
+        assert np.array_equal(fast["wave"], slow["wave"]), name
+        assert ((fast["status"] & FAITHFUL) != 0).all(), name
+        if name == "dbmixer":
+            assert not (fast["status"] & FALLBACK).any()                       # one sequence: nothing reached the general kernel
 
 
 # --------------------------------------- sixteen lanes per instance (group kernel)
@@ -689,9 +719,9 @@ def test_non_convergent_instances_leave_the_fast_path(torch_mod, tmp_path, monke
     assert np.array_equal(fast["step_iters"], slow["step_iters"])
     assert np.array_equal(fast["status"] & NOFB, slow["status"])
     assert rel_err(fast["x"].T, slow["x"].T).max() < TOL
-    assert ((fast["status"][nonconv] & FALLBACK) != 0).all()          # every one of them was handed over
+    assert ((fast["status"][nonconv] & (FALLBACK | FAITHFUL)) != 0).all()          # every one of them left the fast kernel
     conv = np.setdiff1d(np.arange(B), nonconv)
-    assert ((fast["status"][conv] & FALLBACK) == 0).sum() > len(conv) // 2      # and the fast path still ran
+    assert ((fast["status"][conv] & (FALLBACK | FAITHFUL)) == 0).sum() > len(conv) // 2      # and the fast path still ran
     ph = params.cpu().numpy()
     for b in list(nonconv[:3]) + [0]:
         o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, int(b), nl.tstep, nl.tstep * steps, want_rows=False,
