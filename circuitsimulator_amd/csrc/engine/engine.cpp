@@ -410,7 +410,8 @@ int csim_dc_batch_dev(csim_engine* eng, const double* d_params, int32_t B, doubl
         return CSIM_OK;
     }
     hipStream_t hs = static_cast<hipStream_t>(stream);
-    if (eng->schedDcLaunch && eng->kernelChoice != 1) {
+    // (kernel family 3, "faithful": there is no faithful generated DC kernel, the general one is bit-faithful)
+    if (eng->schedDcLaunch && eng->kernelChoice != 1 && eng->kernelChoice != 3) {
         // lane-per-instance kernel on the recorded DC pivot sequences; an instance that fails a pivot
         // check (or meets a non-finite solve) is replayed from x = 0 by the general kernel
         const int rc = ensureFallbackBuffers(eng, B);
