@@ -255,6 +255,44 @@ def test_group_kernel_ragged_batches_chunks_and_probes(engines, torch_mod):
             assert rel_err(got["x"][:, b], o["x_final"]).max() < TOL, (B, b)
 
 
+def _amplifier_line(stages):
+    """Resistively loaded NMOS stages, RC coupled and DC biased: stages MOSFETs, 2*stages + 3 nodes; a
+    well-behaved circuit (5-13 Newton passes per step)."""
+    t = ["* amplifier line", "VDD vdd 0 DC 2.5", "Vin in 0 SIN 0.9 0.05 200e6 0", "Rg in g0 100"]
+    for k in range(stages):
+        t += ["MN%d d%d g%d 0 n 4e-6 1e-6 2" % (k, k, k), "RD%d vdd d%d %g" % (k, k, 4000 + 100 * k),
+              "RC%d d%d g%d %g" % (k, k, k + 1, 3000 + 50 * k), "RB%d g%d 0 %g" % (k, k + 1, 6000 + 100 * k),
+              "CG%d g%d 0 %ge-15" % (k, k + 1, 10 + k)]
+    t += [".MODEL 2 VT 0.55 MU 3e-2 COX 2e-3 LAMBDA 0.04 CJ0 1e-14", ".TRAN 5e-12 2e-9", ".plotnv d%d" % (stages - 1)]
+    return "\n".join(t) + "\n"
+
+
+def test_group_kernel_three_slots_and_two_mosfet_rounds(torch_mod, tmp_path, monkeypatch):
+    """The sixteen-lanes-per-instance kernel beyond the shipped netlists' shape: 33 < N <= 48 unknowns (three
+    rows per lane) and more than 16 MOSFETs (two evaluation rounds per Newton pass), JIT-generated."""
+    from circuitsimulator_amd import Engine, Netlist
+    monkeypatch.setenv("CSIM_JIT_DIR", str(tmp_path / "jit"))
+    nl = Netlist.from_text(_amplifier_line(17))             # 39 unknowns, 17 MOSFETs
+    assert 32 < nl.n_unknowns <= 48 and nl.n_elems > 80
+    eng = Engine(nl, 0)
+    B, steps = 40, 250
+    params = eng.mc_params(11, 0.03, 0, B)
+    slow = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+    eng.jit_scheduled(params, plan_steps=steps)
+    assert eng.tran_kernel == "scheduled" and "group16" in eng.sched_info["text"]
+    res = {}
+    for lanes in (1, 16):
+        eng.set_option("lanes_per_instance", lanes)
+        res[lanes] = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+        assert np.array_equal(res[lanes]["step_iters"], slow["step_iters"]), lanes
+        assert np.array_equal(res[lanes]["status"] & NOFB, slow["status"]), lanes
+        assert rel_err(res[lanes]["x"].T, slow["x"].T).max() < TOL, lanes
+    eng.set_option("lanes_per_instance", 0)
+    assert ((res[16]["status"] & (FALLBACK | FAITHFUL)) == 0).sum() > B // 2      # the group kernel itself did the work
+    o = _orc().tran(nl.ir_ptr, nl.n_unknowns, params.cpu().numpy(), 7, nl.tstep, nl.tstep * steps, want_rows=False)
+    assert res[16]["iters"][7] == o["iters"] and rel_err(res[16]["x"][:, 7], o["x_final"]).max() < TOL
+
+
 def test_group_kernel_hands_over_what_its_one_schedule_does_not_cover(engines, torch_mod):
     """The group kernel carries the FIRST pivot schedule only.  buffer.sp at its shipped step alternates
     between seven: every other factorisation is a violation there and goes through the hybrid stepping
