@@ -210,6 +210,9 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
     termF[static_cast<std::size_t>(ap.termOne)] = termS[static_cast<std::size_t>(ap.termOne)] = LV::konst(1.0);
     termF[static_cast<std::size_t>(ap.termGmin)] = termS[static_cast<std::size_t>(ap.termGmin)] = LV::konst(K.tran_gmin);
     auto PX = [](int slot) { return "params[" + std::to_string(slot) + "LL * SB + bb]"; };
+    // the same parameter as read by the factor block: through an always-zero offset the compiler cannot fold, so that
+    // it does not keep all C/dt of the tape-filling block alive (in scratch) for the factor block's matrix entries
+    auto PF = [](int slot) { return "params[" + std::to_string(slot) + "LL * SB + bb + vo0]"; };
     for (int e = 0; e < ir.n_elems; ++e) {
         const int s = ir.param_slot[e], tb = ap.termBase[static_cast<std::size_t>(e)];
         const int32_t* q = ir.eq + 4 * e;
@@ -217,12 +220,12 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
         switch (ir.kind[e]) {
             case CSIM_R:
                 // used by the factorisation only (once per launch): evaluated where a G entry needs it
-                termF[static_cast<std::size_t>(tb + T_R_G)] = LV::dyn("lin_ginv(" + PX(s) + ")");
+                termF[static_cast<std::size_t>(tb + T_R_G)] = LV::dyn("lin_ginv(" + PF(s) + ")");
                 break;
             case CSIM_C: {
                 const int h = nHandles++;
                 consts << "    { const double pk = lin_gc(" << PX(s) << ", dt); " << st(h) << " }\n";
-                termF[static_cast<std::size_t>(tb + T_C_GC)] = LV::dyn("lin_gc(" + PX(s) + ", dt)");
+                termF[static_cast<std::size_t>(tb + T_C_GC)] = LV::dyn("lin_gc(" + PF(s) + ", dt)");
                 // history current -Gc * vPrev (tanalisis.cpp:77), evaluated where the right-hand side needs it:
                 // the substitution runs at the start of the step, when XL still holds the previous state
                 const std::string v = (q[0] >= 0 && q[1] >= 0) ? "(" + X(q[0]) + " - " + X(q[1]) + ")"
@@ -233,7 +236,7 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
             case CSIM_L: {
                 const int h = nHandles++;
                 consts << "    { const double L = " << PX(s) << "; viol = viol || !(L > 0.0); const double pk = L / dt; " << st(h) << " }\n";
-                termF[static_cast<std::size_t>(tb + T_L_REQ)] = LV::dyn("(" + PX(s) + " / dt)");
+                termF[static_cast<std::size_t>(tb + T_L_REQ)] = LV::dyn("(" + PF(s) + " / dt)");
                 termF[static_cast<std::size_t>(tb + T_L_ONE)] = LV::konst(1.0);
                 const int kb = ir.branch_eq[e];
                 termS[static_cast<std::size_t>(tb + T_L_VH)] = LV::dyn("(-" + rd(h) + " * " + X((kb >= 0 && kb < N) ? kb : -1) + ")");
@@ -433,10 +436,10 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
     }
     // The step reads the tape strictly in order, one miss of ~700 cycles each if it waits for every entry
     // where it is used (measured: 454 us per step on the N = 257 ladder, 1539 sequential misses).  So the
-    // entries are loaded into registers two chunks of 48 ahead of their use: loads of chunk c+2 are issued
+    // entries are loaded into registers two chunks of 32 ahead of their use: loads of chunk c+2 are issued
     // where chunk c is first needed, and the scheduling barriers keep them there.
     {
-        const int chunk = 48;
+        const int chunk = 32;
         std::vector<std::string> lines;
         {
             std::size_t i = 0;
@@ -510,6 +513,7 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
       << "#define TW(n) tapeW[(n) * " << LPW << "]\n"
       << "#define TP(n) tapeR[(n) * " << LPW << "]\n"
       << "    bool viol = false;\n"
+      << "    const long long vo0 = splitFlag ? 1LL : 0LL;       // always 0, opaque\n"
       << "    {\n        const double* xin = xio + bb;\n#pragma unroll 1\n"
       << "        for (int i = 0; i < " << N << "; ++i, xin += SB) XL(i) = *xin;\n    }\n"
       << "    // launch constants (tanalisis.cpp:65-67,296) and the factors -> the tape\n"
