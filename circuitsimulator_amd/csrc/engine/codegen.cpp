@@ -1047,10 +1047,10 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     }
     const bool haveDc = ldsDc >= 0;
 
-    // sixteen lanes per instance (group_plan.hpp): the first (most frequent) schedule only; any other
-    // sequence is a violation there and goes through the hybrid stepping
+    // sixteen lanes per instance (group_plan.hpp): one solve body per schedule over the first one's row
+    // placement; a sequence none of them covers is a violation and goes through the hybrid stepping
     GroupPlan groupPlan;
-    const std::string groupSrc = emitGroupKernel(ir, ap, set.alts[0], gopt, &groupPlan);
+    const std::string groupSrc = emitGroupKernel(ir, ap, set.alts, gopt, &groupPlan);
     const bool haveGroup = !groupSrc.empty();
     src << groupSrc;
 
@@ -1074,7 +1074,7 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "extern \"C\" int csim_sched_work_doubles(void) { return " << (haveLinear ? linWork : 0) << "; }\n"
         << "// 1 when this library carries csim_tran_faithful_kernel (csim_sched_launch variant 3)\n"
         << "extern \"C\" int csim_sched_has_faithful(void) { return " << (haveFaithful ? 1 : 0) << "; }\n"
-        << "// 16 when this library also carries csim_tran_group_kernel (sixteen lanes per instance, first schedule only)\n"
+        << "// 16 when this library also carries csim_tran_group_kernel (sixteen lanes per instance, one solve body per schedule)\n"
         << "extern \"C\" int csim_sched_group_lanes(void) { return " << (haveGroup ? 16 : 0) << "; }\n";
     src << ""
         << "// the recorded alternatives, [n_alts][N] pivot row positions (the engine hands them to the\n"

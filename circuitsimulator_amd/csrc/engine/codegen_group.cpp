@@ -152,13 +152,27 @@ __device__ __forceinline__ void grp_mos_eval(double p, double Vth, double K, dou
 
 } // namespace
 
-std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch,
+std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std::vector<PivotSchedule>& schedules,
                             const GeneratorOptions& gopt, GroupPlan* planOut)
 {
     (void)gopt;       // no scheduling barriers here: 270 registers, nothing spills, the scheduler may roam
-    GroupPlan gp;
-    if (!buildGroupPlan(ir, ap, sch, gp)) return std::string();
+    if (schedules.empty()) return std::string();
+    // The first (most frequent) schedule places the rows; the others are planned over that placement, so
+    // that all solve bodies share the launch-constant matrix part, the staging rows and the scatter tables.
+    std::vector<GroupPlan> plans(1);
+    if (!buildGroupPlan(ir, ap, schedules[0], plans[0])) return std::string();
+    for (std::size_t a = 1; a < schedules.size(); ++a) {
+        GroupPlan alt;
+        if (!buildGroupPlan(ir, ap, schedules[a], alt, &plans[0])) return std::string();
+        if (alt.gCellPtr != plans[0].gCellPtr || alt.gCellCon != plans[0].gCellCon || alt.iCellPtr != plans[0].iCellPtr ||
+            alt.iCellCon != plans[0].iCellCon || alt.mosDest != plans[0].mosDest || alt.stageRows.size() != plans[0].stageRows.size() ||
+            alt.gClasses.size() != plans[0].gClasses.size())
+            return std::string();                              // cannot happen: the tables depend on the placement only
+        plans.push_back(alt);
+    }
+    const GroupPlan& gp = plans[0];
     if (planOut) *planOut = gp;
+    const bool multi = plans.size() > 1;
     const int N = gp.N, S = gp.S, G = kGroupLanes;
     const csim_consts& K = ir.k;
     const int NP = S * G;                                       // padded unknown count
@@ -238,7 +252,10 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
     o << intArray("grp_src", srcTab) << intArray("grp_hA", hA) << intArray("grp_hG", hG) << intArray("grp_rhs", rhsIdx);
 
     o << "\n// One DPP row of 16 lanes = one circuit instance, 4 instances per wavefront (group_plan.hpp).\n"
-      << "// pivot schedule: " << (sch.str().empty() ? std::string("-") : sch.str()) << "\n"
+      << "// pivot schedule" << (multi ? "s, tried in this order" : "") << ": " << [&] {
+             std::string all;
+             for (std::size_t a = 0; a < schedules.size(); ++a) all += (a ? " ; " : "") + (schedules[a].str().empty() ? std::string("-") : schedules[a].str());
+             return all; }() << "\n"
       << "extern \"C\" __global__ void __launch_bounds__(64)\n"
       << "csim_tran_group_kernel(const double* __restrict__ params, int B, double dt, long long stepFirst,\n"
       << "                       long long nSteps, const int* __restrict__ probeEq, int nProbe, int outStride,\n"
@@ -388,12 +405,25 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
     // may alias).  A __syncthreads() would add nothing but a scheduling barrier and a full lgkmcnt(0) wait
     // (measured: 30 % of the wave's cycles in s_waitcnt with four of them per iteration).
 
+    // ---- one solve: assembly, elimination with the plan's pivots, back substitution into <xname><slot>
+    auto maskName = [&](const GroupPlan::Column::SlotMask& m) -> std::string {
+        if (m.keepAll) return std::string();
+        if (m.suffix >= 0) return "mk" + std::to_string(m.suffix);
+        char buf[48];
+        std::snprintf(buf, sizeof buf, "(((0x%04x >> g) & 1) ? 1.0 : 0.0)", m.lanes & 0xFFFFu);
+        return buf;
+    };
+    auto maskFactor = [&](const GroupPlan::Column::SlotMask& m) -> std::string {
+        const std::string n = maskName(m);
+        return n.empty() ? n : " * " + n;
+    };
+    auto emitSolve = [&](const GroupPlan& pl, const std::string& in, const std::string& xname) -> bool {
     // ---- assembly: class registers
     o << in << "// assembly: (terms constant within the step) + (MOSFET terms from the staging rows, in stamping order)\n";
     std::vector<std::vector<char>> declared(static_cast<std::size_t>(S), std::vector<char>(static_cast<std::size_t>(N + 1), 0));
     for (int s = 0; s < S; ++s)
         for (int j = 0; j <= N; ++j) {
-            if (!gp.classLive[static_cast<std::size_t>(s)][static_cast<std::size_t>(j)]) continue;
+            if (!pl.classLive[static_cast<std::size_t>(s)][static_cast<std::size_t>(j)]) continue;
             declared[static_cast<std::size_t>(s)][static_cast<std::size_t>(j)] = 1;
             std::string init = "0.0";
             if (j == N) init = "cb" + std::to_string(s);
@@ -401,8 +431,8 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
             o << in << "double a_" << s << "_" << j << " = " << init << ";\n";
         }
     for (int r = 0; r < nStage; ++r) {
-        const GroupPlan::StageRow& sr = gp.stageRows[static_cast<std::size_t>(r)];
-        if (!declared[static_cast<std::size_t>(sr.s)][static_cast<std::size_t>(sr.j)]) return std::string();   // cannot happen: a staged cell is live
+        const GroupPlan::StageRow& sr = pl.stageRows[static_cast<std::size_t>(r)];
+        if (!declared[static_cast<std::size_t>(sr.s)][static_cast<std::size_t>(sr.j)]) return false;   // cannot happen: a staged cell is live
         o << in << "a_" << sr.s << "_" << sr.j << " += ST[" << r * G << " + g];\n";
     }
 
@@ -410,8 +440,8 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
     o << in << "double worst = -1.0, tie = -1.0;   // pivot checks of this lane's rows (see the first column)\n";
     std::vector<std::string> rinv(static_cast<std::size_t>(N));
     for (int k = 0; k < N; ++k) {
-        const GroupPlan::Column& col = gp.cols[static_cast<std::size_t>(k)];
-        const int sk = k / G, lk = k % G;
+        const GroupPlan::Column& col = pl.cols[static_cast<std::size_t>(k)];
+        const int sk = col.pivSlot, lk = col.pivLane;
         const std::string ak = "a_" + std::to_string(sk) + "_" + std::to_string(k);
         o << in << "// column " << k << ": pivot row = lane " << lk << ", slot " << sk << "\n";
         if (col.zeroPivot || col.contradiction) {
@@ -445,7 +475,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
             for (int s = 0; s < S; ++s) {
                 if (!anyOf[static_cast<std::size_t>(s)]) continue;
                 const std::string d = "dc" + std::to_string(k) + "_" + std::to_string(s);
-                o << in << "const double " << d << " = fabs(a_" << s << "_" << k << ")" << (s == sk ? " * mk" + std::to_string(lk) : std::string())
+                o << in << "const double " << d << " = fabs(a_" << s << "_" << k << ")" << maskFactor(col.checkMask[static_cast<std::size_t>(s)])
                   << " - " << absP << ";\n"
                   << in << "worst = fmax(worst, " << d << ");\n";
                 if (strictOf[static_cast<std::size_t>(s)]) {
@@ -461,17 +491,19 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
         }
         if (col.lSlots.empty()) continue;
         // multipliers (solver.hpp:71); finished rows of the slot being consumed get an exact 0
-        for (int s : col.lSlots) {
+        for (std::size_t li = 0; li < col.lSlots.size(); ++li) {
+            const int s = col.lSlots[li];
             const std::string as = "a_" + std::to_string(s) + "_" + std::to_string(k);
             std::string e;
-            const bool masked = s == sk;
+            const std::string mf = maskName(col.lMask[li]);
+            const bool masked = !mf.empty();
             if (col.pivotConst) {
                 const double rc = 1.0 / col.pivotValue;
-                if (rc == 1.0) e = masked ? as + " * mk" + std::to_string(lk) : as;
-                else if (rc == -1.0) e = masked ? "-(" + as + " * mk" + std::to_string(lk) + ")" : "-" + as;
-                else e = masked ? as + " * (" + lit(rc) + " * mk" + std::to_string(lk) + ")" : as + " * " + lit(rc);
+                if (rc == 1.0) e = masked ? as + " * " + mf : as;
+                else if (rc == -1.0) e = masked ? "-(" + as + " * " + mf + ")" : "-" + as;
+                else e = masked ? as + " * (" + lit(rc) + " * " + mf + ")" : as + " * " + lit(rc);
             } else {
-                e = masked ? as + " * (r" + std::to_string(k) + " * mk" + std::to_string(lk) + ")" : as + " * r" + std::to_string(k);
+                e = masked ? as + " * (r" + std::to_string(k) + " * " + mf + ")" : as + " * r" + std::to_string(k);
             }
             o << in << "const double f" << k << "_" << s << " = " << e << ";\n";
         }
@@ -484,7 +516,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
             }
             for (int s : col.lSlots) {
                 const std::string t = "a_" + std::to_string(s) + "_" + std::to_string(u.j);
-                if (!declared[static_cast<std::size_t>(s)][static_cast<std::size_t>(u.j)]) return std::string();   // fill into a class the plan did not mark
+                if (!declared[static_cast<std::size_t>(s)][static_cast<std::size_t>(u.j)]) return false;   // fill into a class the plan did not mark
                 const std::string f = "f" + std::to_string(k) + "_" + std::to_string(s);
                 if (u.isConst && u.c == 1.0) o << in << t << " = " << t << " - " << f << ";\n";
                 else if (u.isConst && u.c == -1.0) o << in << t << " = " << t << " + " << f << ";\n";
@@ -494,15 +526,39 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
     }
 
     // ---- back substitution, column-wise (solver.hpp:116-128)
-    o << in << "// back substitution: x_j is formed in lane j % 16, broadcast, and subtracted from the rows above\n";
-    for (int s = 0; s < S; ++s) o << in << "double xr" << s << " = 0.0;\n";
+    o << in << "// back substitution: x_j is formed in the lane of column j's pivot row, broadcast, and subtracted from the rows\n"
+      << in << "// pivoted before it; lane j % 16 keeps it as its solution entry\n";
+    for (int s = 0; s < S; ++s) o << in << "double " << xname << s << " = 0.0;\n";
     for (int j = N - 1; j >= 0; --j) {
-        const int sj = j / G, lj = j % G;
-        o << in << "const double xt" << j << " = a_" << sj << "_" << N << " * " << rinv[static_cast<std::size_t>(j)] << ";\n"
-          << in << "xr" << sj << " = (g == " << lj << ") ? xt" << j << " : xr" << sj << ";      // lane " << lj << " keeps its own solution entry\n"
-          << in << "const double xb" << j << " = grp_bc<" << lj << ">(xt" << j << ");\n";
-        for (int s : gp.backSlots[static_cast<std::size_t>(j)])
+        const int sj = pl.cols[static_cast<std::size_t>(j)].pivSlot, lj = pl.cols[static_cast<std::size_t>(j)].pivLane;
+        const bool home = sj == j / G && lj == j % G;              // the pivot row sits where x_j is kept (first schedule: always)
+        o << in << "const double xt" << j << " = a_" << sj << "_" << N << " * " << rinv[static_cast<std::size_t>(j)] << ";\n";
+        if (home)
+            o << in << xname << sj << " = (g == " << lj << ") ? xt" << j << " : " << xname << sj << ";      // lane " << lj << " keeps its own solution entry\n";
+        o << in << "const double xb" << j << " = grp_bc<" << lj << ">(xt" << j << ");\n";
+        if (!home)
+            o << in << xname << j / G << " = (g == " << j % G << ") ? xb" << j << " : " << xname << j / G << ";\n";
+        for (int s : pl.backSlots[static_cast<std::size_t>(j)])
             o << in << "a_" << s << "_" << N << " = a_" << s << "_" << N << " - a_" << s << "_" << j << " * xb" << j << ";\n";
+    }
+    return true;
+    };
+
+    if (!multi) {
+        if (!emitSolve(plans[0], in, "xr")) return std::string();
+    } else {
+        // every schedule gets its own body; a later one runs only while some group's checks failed in all
+        // earlier ones (the lane-per-instance kernel does the same, codegen.cpp)
+        for (int s = 0; s < S; ++s) o << in << "double xr" << s << " = 0.0;\n";
+        o << in << "bool pv = true;\n";
+        for (std::size_t a = 0; a < plans.size(); ++a) {
+            o << in << (a ? "if (__any(active && pv)) " : "") << "{   // schedule " << a << "\n";
+            if (!emitSolve(plans[a], in + "    ", "xa")) return std::string();
+            o << in << "    const bool pva = (__ballot(worst > 0.0 || tie >= 0.0) & rowBits) != 0ull;\n";
+            for (int s = 0; s < S; ++s) o << in << "    xr" << s << " = pv ? xa" << s << " : xr" << s << ";\n";
+            o << in << "    pv = pv && pva;\n"
+              << in << "}\n";
+        }
     }
 
     // ---- damped update, norm, convergence (tanalisis.cpp:360-376)
@@ -512,7 +568,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const Piv
           << in << "{ const double d = xn" << s << " - xo" << s << "; ss += d * d; }\n";
     o << in << "ss = grp_sum16(ss);\n"
       << in << "const double err = sqrt(ss);\n"
-      << in << "const bool pv = (__ballot(worst > 0.0 || tie >= 0.0) & rowBits) != 0ull;\n"
+      << (multi ? std::string() : in + "const bool pv = (__ballot(worst > 0.0 || tie >= 0.0) & rowBits) != 0ull;\n")
       << in << "// branch-free bookkeeping (everything here is uniform within a group of 16 lanes)\n"
       << in << "const bool good = active && !pv && (ss < 1.0e300);      // the solve stands: take the damped update\n"
       << in << "const bool conv = err < " << lit(K.tran_tol) << ";\n"

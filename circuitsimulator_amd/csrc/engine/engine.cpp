@@ -363,10 +363,9 @@ static int schedVariantFor(const csim_engine* eng, int32_t B)
     if (eng->cfg.lanesPerInstance == 1) return 0;
     // auto: sixteen lanes per instance while the batch is too small to give every SIMD a wave of 64
     // instances (measured on dbmixer: 16 lanes 1.9e9 NR-iter*inst/s from B = 4096 up, one lane
-    // 8.5e8 at B = 4096 growing linearly to 1.2e10 at B = 65 536: they cross near B = 9000).  The
-    // group kernel carries the first pivot schedule only, so a circuit that alternates between
-    // several (buffer.sp at its shipped step) stays on the lane-per-instance kernel.
-    return (eng->schedGroupLanes == 16 && eng->nKnownAlts == 1 && B <= 8192) ? 16 : 0;
+    // 8.5e8 at B = 4096 growing linearly to 1.2e10 at B = 65 536: they cross near B = 9000).  Both
+    // kernels carry the same set of pivot schedules.
+    return (eng->schedGroupLanes == 16 && B <= 8192) ? 16 : 0;
 }
 
 extern "C" int csim_engine_lanes_for_batch(const csim_engine* eng, int32_t B)

@@ -29,7 +29,8 @@ int mosStampKind(int termOffset, bool neg)
 
 } // namespace
 
-bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch, GroupPlan& gp)
+bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch, GroupPlan& gp,
+                    const GroupPlan* placement)
 {
     const int N = ir.n_unknowns;
     gp = GroupPlan();
@@ -89,15 +90,22 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
     for (int i = 0; i < N; ++i) cur[static_cast<std::size_t>(i)] = i;
     gp.finalPos.assign(static_cast<std::size_t>(N), -1);
     gp.rowAtPos.assign(static_cast<std::size_t>(N), -1);
+    std::vector<int> pivotStep(static_cast<std::size_t>(N), -1);         // original row -> column it is the pivot of
     {
         std::vector<int> c2 = cur;
         for (int k = 0; k < N; ++k) {
             const int p = sch.pivotPos[static_cast<std::size_t>(k)];
             if (p < k || p >= N) return false;
             std::swap(c2[static_cast<std::size_t>(k)], c2[static_cast<std::size_t>(p)]);
-            gp.finalPos[static_cast<std::size_t>(c2[static_cast<std::size_t>(k)])] = k;
-            gp.rowAtPos[static_cast<std::size_t>(k)] = c2[static_cast<std::size_t>(k)];
+            pivotStep[static_cast<std::size_t>(c2[static_cast<std::size_t>(k)])] = k;
         }
+    }
+    if (placement) {
+        if (placement->N != N) return false;
+        gp.finalPos = placement->finalPos;
+        gp.rowAtPos = placement->rowAtPos;
+    } else {
+        for (int r = 0; r < N; ++r) { gp.finalPos[static_cast<std::size_t>(r)] = pivotStep[static_cast<std::size_t>(r)]; gp.rowAtPos[static_cast<std::size_t>(pivotStep[static_cast<std::size_t>(r)])] = r; }
     }
     auto slotOf = [&](int row) { return gp.finalPos[static_cast<std::size_t>(row)] / kGroupLanes; };
     auto laneOf = [&](int row) { return gp.finalPos[static_cast<std::size_t>(row)] % kGroupLanes; };
@@ -122,6 +130,26 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
         if (pv.zero()) col.zeroPivot = true;
         col.pivotConst = pv.k == Kind::CONST;
         col.pivotValue = pv.c;
+        col.pivLane = laneOf(P);
+        col.pivSlot = slotOf(P);
+        // rows still unpivoted after this column, per slot (an update or a candidate test may touch only those)
+        auto maskOf = [&](int s) {
+            GroupPlan::Column::SlotMask m;
+            bool anyGone = false;
+            for (int lane = 0; lane < kGroupLanes; ++lane) {
+                const int pos = s * kGroupLanes + lane;
+                if (pos >= N) { m.lanes |= 1u << lane; continue; }            // no row there: its registers are exact zeros
+                const int R2 = gp.rowAtPos[static_cast<std::size_t>(pos)];
+                if (pivotStep[static_cast<std::size_t>(R2)] > k) m.lanes |= 1u << lane;
+                else anyGone = true;
+            }
+            m.keepAll = !anyGone;
+            for (int t = 0; t < kGroupLanes && !m.keepAll; ++t)
+                if (m.lanes == ((0xFFFFu << (t + 1)) & 0xFFFFu)) m.suffix = t;
+            return m;
+        };
+        col.checkMask.resize(static_cast<std::size_t>(S));
+        for (int s = 0; s < S; ++s) col.checkMask[static_cast<std::size_t>(s)] = maskOf(s);
         // the reference picks the FIRST row attaining the column maximum (solver.hpp:48-56): rows before the
         // scheduled one must be strictly smaller, rows after it not larger; tiny pivot fails (:58-61)
         std::map<std::pair<int, bool>, unsigned> groups;
@@ -179,10 +207,10 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
         for (int s = 0; s < S; ++s)
             if (slotHasL[static_cast<std::size_t>(s)]) {
                 col.lSlots.push_back(s);
-                ++gp.nMul;
+                col.lMask.push_back(col.checkMask[static_cast<std::size_t>(s)]);
+                gp.nMul += col.lMask.back().keepAll ? 1 : 2;
                 gp.nFma += static_cast<int>(col.u.size());
             }
-        if (!col.lSlots.empty() && std::find(col.lSlots.begin(), col.lSlots.end(), k / kGroupLanes) != col.lSlots.end()) ++gp.nMul;
         markLive();
     }
 
@@ -190,10 +218,9 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
     gp.backSlots.assign(static_cast<std::size_t>(N), {});
     for (int j = 0; j < N; ++j) {
         std::vector<char> has(static_cast<std::size_t>(S), 0);
-        for (int i = 0; i < j; ++i) {
-            const int R = gp.rowAtPos[static_cast<std::size_t>(i)];
-            if (!M[static_cast<std::size_t>(R)][static_cast<std::size_t>(j)].zero()) has[static_cast<std::size_t>(i / kGroupLanes)] = 1;
-        }
+        for (int R = 0; R < N; ++R)
+            if (pivotStep[static_cast<std::size_t>(R)] < j && !M[static_cast<std::size_t>(R)][static_cast<std::size_t>(j)].zero())
+                has[static_cast<std::size_t>(slotOf(R))] = 1;
         for (int s = 0; s < S; ++s)
             if (has[static_cast<std::size_t>(s)]) { gp.backSlots[static_cast<std::size_t>(j)].push_back(s); ++gp.nFma; }
         gp.nMul += 1;
@@ -273,13 +300,14 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
         std::vector<int> tr(static_cast<std::size_t>(N), 0);
         for (int k = 0; k < N; ++k) {
             const GroupPlan::Column& col = gp.cols[static_cast<std::size_t>(k)];
-            const int sk = k / kGroupLanes;
+            const int sk = col.pivSlot;
             int r = 0;
             if (!col.pivotConst) r = t[static_cast<std::size_t>(sk)][static_cast<std::size_t>(k)] + lat + latRcp;
             tr[static_cast<std::size_t>(k)] = r;
             std::vector<int> tf(static_cast<std::size_t>(S), 0);
-            for (int s : col.lSlots) {
-                const int rr = (s == sk && !col.pivotConst) ? r + lat : r;      // r * mk
+            for (std::size_t li = 0; li < col.lSlots.size(); ++li) {
+                const int s = col.lSlots[li];
+                const int rr = (!col.lMask[li].keepAll && !col.pivotConst) ? r + lat : r;      // r * mask
                 tf[static_cast<std::size_t>(s)] = std::max(t[static_cast<std::size_t>(s)][static_cast<std::size_t>(k)], rr) + lat;
             }
             for (const GroupPlan::UEntry& u : col.u) {
@@ -293,7 +321,7 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
         gp.depthElimination = 0;
         for (int s = 0; s < S; ++s) for (int j = 0; j <= N; ++j) gp.depthElimination = std::max(gp.depthElimination, t[static_cast<std::size_t>(s)][static_cast<std::size_t>(j)]);
         for (int j = N - 1; j >= 0; --j) {
-            const int sj = j / kGroupLanes;
+            const int sj = gp.cols[static_cast<std::size_t>(j)].pivSlot;
             const int tx = std::max(t[static_cast<std::size_t>(sj)][static_cast<std::size_t>(N)], tr[static_cast<std::size_t>(j)]) + lat + lat;
             worst = std::max(worst, tx);
             for (int s : gp.backSlots[static_cast<std::size_t>(j)]) {
@@ -319,8 +347,9 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
 
 // ---------------------------------------------------------------- interpreter
 void interpretGroupPlan(const GroupPlan& gp, const AssemblyPlan& ap, const csim_ir& ir, const double* T, double eps,
-                        double* x, bool* violated)
+                        double* x, bool* violated, bool* planError)
 {
+    bool wrongPlan = false;
     (void)ir;
     const int N = gp.N, S = gp.S, G = kGroupLanes;
     // registers a[s][j][lane]
@@ -360,7 +389,7 @@ void interpretGroupPlan(const GroupPlan& gp, const AssemblyPlan& ap, const csim_
     bool bad = false;
     for (int k = 0; k < N; ++k) {
         const GroupPlan::Column& col = gp.cols[static_cast<std::size_t>(k)];
-        const int sk = k / G, lk = k % G;
+        const int sk = col.pivSlot, lk = col.pivLane;
         if (col.zeroPivot || col.contradiction) { bad = true; continue; }
         const double pb = A(sk, k, lk);                                   // broadcast
         if (!col.pivotConst && !(std::fabs(pb) >= eps)) bad = true;
@@ -370,20 +399,35 @@ void interpretGroupPlan(const GroupPlan& gp, const AssemblyPlan& ap, const csim_
                     const double v = std::fabs(A(c.slot, k, lane));
                     if (!(c.strict ? std::fabs(pb) > v : std::fabs(pb) >= v)) bad = true;
                 }
-        const double r = 1.0 / pb;
-        for (int s : col.lSlots)
+        // what the kernel tests on EVERY lane of the slots that hold candidates must not fire on the others:
+        // finished rows are masked, rows without an entry hold an exact zero
+        for (int s = 0; s < S; ++s) {
+            bool any = false;
+            for (const GroupPlan::Check& c : col.checks) any = any || c.slot == s;
+            if (!any) continue;
             for (int lane = 0; lane < G; ++lane) {
-                const double mask = (s == sk) ? (lane > lk ? 1.0 : 0.0) : 1.0;
-                const double f = A(s, k, lane) * (r * mask);
+                bool isCand = false;
+                for (const GroupPlan::Check& c : col.checks) isCand = isCand || (c.slot == s && (c.laneMask & (1u << lane)));
+                const bool kept = col.checkMask[static_cast<std::size_t>(s)].keepAll || (col.checkMask[static_cast<std::size_t>(s)].lanes & (1u << lane));
+                if (!isCand && kept && !(s == sk && lane == lk) && A(s, k, lane) != 0.0) wrongPlan = true;   // would be tested
+            }
+        }
+        const double r = 1.0 / pb;
+        for (std::size_t li = 0; li < col.lSlots.size(); ++li) {
+            const int s = col.lSlots[li];
+            for (int lane = 0; lane < G; ++lane) {
+                const bool keep = col.lMask[li].keepAll || (col.lMask[li].lanes & (1u << lane));
+                const double f = A(s, k, lane) * (r * (keep ? 1.0 : 0.0));
                 for (const GroupPlan::UEntry& u : col.u) {
                     const double ub = u.isConst ? u.c : A(sk, u.j, lk);
                     A(s, u.j, lane) = A(s, u.j, lane) - f * ub;
                 }
             }
+        }
     }
     for (int j = N - 1; j >= 0; --j) {
         const GroupPlan::Column& col = gp.cols[static_cast<std::size_t>(j)];
-        const int sj = j / G, lj = j % G;
+        const int sj = col.pivSlot, lj = col.pivLane;
         const double piv = A(sj, j, lj);
         const double xj = (col.zeroPivot || col.contradiction) ? 0.0 : A(sj, N, lj) * (1.0 / piv);
         x[j] = xj;
@@ -391,6 +435,7 @@ void interpretGroupPlan(const GroupPlan& gp, const AssemblyPlan& ap, const csim_
             for (int lane = 0; lane < G; ++lane) A(s, N, lane) = A(s, N, lane) - A(s, j, lane) * xj;
     }
     if (violated) *violated = bad;
+    if (planError) *planError = wrongPlan;
 }
 
 } // namespace csim

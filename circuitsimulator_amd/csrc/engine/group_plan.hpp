@@ -52,6 +52,13 @@ struct GroupPlan {
     struct Check { int slot; bool strict; unsigned laneMask; };     // |pivot| > (strict) or >= |a[slot][k]| on these lanes
     struct UEntry { int j; bool isConst; double c; };                // pivot-row entry right of the diagonal (j == N: rhs)
     struct Column {
+        int pivLane = 0, pivSlot = 0;        // where the pivot row of this column sits (first schedule: k%16, k/16)
+        // per slot of lSlots: the lanes whose rows are still unpivoted after this column (the rows an update
+        // may touch); keepAll = no finished row and no pivot row in the slot (no factor needed); suffix >= 0:
+        // the mask is "lane > suffix" (the launch-constant factors mk<suffix>)
+        struct SlotMask { unsigned lanes = 0; bool keepAll = false; int suffix = -1; };
+        std::vector<SlotMask> lMask;         // parallel to lSlots
+        std::vector<SlotMask> checkMask;     // per slot s (size S): the same notion for the candidates' magnitudes
         bool zeroPivot = false;              // scheduled pivot is a structural zero: always a violation
         bool contradiction = false;          // schedule contradicts exact constants: always a violation
         bool pivotConst = false;             // pivot is an exact constant (rinv is a literal, no eps test)
@@ -61,7 +68,7 @@ struct GroupPlan {
         std::vector<UEntry> u;
     };
     std::vector<Column> cols;
-    std::vector<std::vector<int>> backSlots; // [j]: slots with rows above position j whose U(i,j) may be non-zero
+    std::vector<std::vector<int>> backSlots; // [j]: slots with rows pivoted before column j whose U(i,j) may be non-zero
     std::vector<std::vector<uint8_t>> classLive;   // [s][j], j <= N: the register class is ever non-zero
 
     // ---- assembly
@@ -87,18 +94,25 @@ struct GroupPlan {
     int depthElimination = 0, depthSolve = 0;
 };
 
-// false: the circuit does not fit this kernel (N > 48, no Newton terms to stage, ...)
-bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch, GroupPlan& out);
+// false: the circuit does not fit this kernel (N > 48, ...).  placement: where the rows sit.  The first
+// schedule of a circuit places them itself (row of final pivot position p at lane p%16, slot p/16); further
+// alternatives are planned over THAT placement (placement = the first plan), so that they share the
+// step-constant matrix part and the MOSFET staging: their pivot rows then sit at arbitrary lanes and the
+// finished rows of a slot are no longer a lane prefix (explicit lane masks instead of the mk factors).
+bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch, GroupPlan& out,
+                    const GroupPlan* placement = nullptr);
 
 // Host interpreter of the plan, lane by lane, for ONE system: T[nTerms] are the term values of
-// plan.hpp.  Writes x[N]; *violated = a pivot check failed.  Used by the self test
+// plan.hpp.  Writes x[N]; *violated = a pivot check failed; *planError = a lane the kernel's all-lane
+// candidate test would see is neither a candidate, masked, nor an exact zero.  Used by the self test
 // (csim_codegen --selftest-group) to validate masks, placement, staging and substitution order
 // against a plain pivoted elimination, without a GPU.
 void interpretGroupPlan(const GroupPlan& gp, const AssemblyPlan& ap, const csim_ir& ir, const double* T, double eps,
-                        double* x, bool* violated);
+                        double* x, bool* violated, bool* planError = nullptr);
 
-// the __global__ kernel "csim_tran_group_kernel" + its tables; "" if the circuit does not fit
-std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch,
+// the __global__ kernel "csim_tran_group_kernel" + its tables; "" if the circuit does not fit.  One solve
+// body per schedule, tried in order per Newton pass for the groups whose checks failed so far.
+std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std::vector<PivotSchedule>& schedules,
                             const GeneratorOptions& gopt, GroupPlan* planOut);
 
 } // namespace csim

@@ -41,9 +41,12 @@ static int selftestGroup(const csim_ir* ir, const csim::AssemblyPlan& ap, const 
 {
     int worstAlt = -1;
     double worst = 0.0;
+    csim::GroupPlan first;
     for (std::size_t alt = 0; alt < sch.alts.size(); ++alt) {
         csim::GroupPlan gp;
-        if (!csim::buildGroupPlan(*ir, ap, sch.alts[alt], gp)) { std::printf("group plan: circuit does not fit\n"); return 3; }
+        // as the emitter does: alternatives are planned over the first schedule's row placement
+        if (!csim::buildGroupPlan(*ir, ap, sch.alts[alt], gp, alt ? &first : nullptr)) { std::printf("group plan: circuit does not fit\n"); return 3; }
+        if (alt == 0) first = gp;
         const int N = ir->n_unknowns, LD = ap.LD;
         unsigned long long seed = 0x9E3779B97F4A7C15ull + alt;
         auto rnd = [&seed]() { seed = seed * 6364136223846793005ull + 1442695040888963407ull; return (double)((seed >> 11) & 0xFFFFFFFFull) / 4294967296.0; };
@@ -92,8 +95,9 @@ static int selftestGroup(const csim_ir* ir, const csim::AssemblyPlan& ap, const 
                 for (int j = i + 1; j < N; ++j) sum -= A[(std::size_t)i * (N + 1) + j] * xr[(std::size_t)j];
                 xr[(std::size_t)i] = sum / A[(std::size_t)i * (N + 1) + i];
             }
-            bool viol = false;
-            csim::interpretGroupPlan(gp, ap, *ir, T.data(), 1e-15, xg.data(), &viol);
+            bool viol = false, planError = false;
+            csim::interpretGroupPlan(gp, ap, *ir, T.data(), 1e-15, xg.data(), &viol, &planError);
+            if (planError) { std::printf("group plan alt %zu: a candidate test would see a row it must not\n", alt); return 5; }
             for (int i = 0; i < N; ++i) {
                 const double e = std::fabs(xg[(std::size_t)i] - xr[(std::size_t)i]) / std::max(std::fabs(xr[(std::size_t)i]), 1e-6);
                 if (e > worst) { worst = e; worstAlt = (int)alt; }
