@@ -64,7 +64,9 @@ struct ScheduleSet {
 struct GeneratorOptions {
     int barrierEvery = 3;        // scheduling barrier every n-th elimination column (0 = none)
     std::vector<int> sweep;      // tuning aid: extra kernels csim_tran_sched_kernel_sweep<k> (see codegen.cpp)
-    bool set(const std::string& keyval);      // "barrier_every=3", "sweep=0,16,32"
+    int stageAhead = 3;          // sixteen-lane kernel: a staging row is read this many columns before the column
+                                 // that first needs it (-1: all rows read and added before the elimination)
+    bool set(const std::string& keyval);      // "barrier_every=3", "sweep=0,16,32", "stage_ahead=3"
 };
 
 // bumped whenever the emitted code or the launcher ABI of a generated library changes

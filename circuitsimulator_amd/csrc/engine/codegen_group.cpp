@@ -155,7 +155,6 @@ __device__ __forceinline__ void grp_mos_eval(double p, double Vth, double K, dou
 std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std::vector<PivotSchedule>& schedules,
                             const GeneratorOptions& gopt, GroupPlan* planOut)
 {
-    (void)gopt;       // no scheduling barriers here: 270 registers, nothing spills, the scheduler may roam
     if (schedules.empty()) return std::string();
     // The first (most frequent) schedule places the rows; the others are planned over that placement, so
     // that all solve bodies share the launch-constant matrix part, the staging rows and the scatter tables.
@@ -430,11 +429,43 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
             else if (classOf[static_cast<std::size_t>(s)][static_cast<std::size_t>(j)] >= 0) init = "c_" + std::to_string(s) + "_" + std::to_string(j);
             o << in << "double a_" << s << "_" << j << " = " << init << ";\n";
         }
-    for (int r = 0; r < nStage; ++r) {
-        const GroupPlan::StageRow& sr = pl.stageRows[static_cast<std::size_t>(r)];
-        if (!declared[static_cast<std::size_t>(sr.s)][static_cast<std::size_t>(sr.j)]) return false;   // cannot happen: a staged cell is live
-        o << in << "a_" << sr.s << "_" << sr.j << " += ST[" << r * G << " + g];\n";
+    for (int r = 0; r < nStage; ++r)
+        if (!declared[static_cast<std::size_t>(pl.stageRows[static_cast<std::size_t>(r)].s)][static_cast<std::size_t>(pl.stageRows[static_cast<std::size_t>(r)].j)])
+            return false;                                              // cannot happen: a staged cell is live
+    // A staging row is read a few columns before the column that first touches its class and added right
+    // there: issued up front, the reads end up one after the other, each waited for (the kernel sits at the
+    // 256 architectural registers, so the compiler reuses one landing register: 13 LDS round trips, 28 % of
+    // the wave's cycles); spread over the elimination they overlap with it.
+    std::vector<int> firstUse(static_cast<std::size_t>(nStage), N);   // column whose code first reads/writes the class
+    {
+        std::vector<std::vector<int>> fu(static_cast<std::size_t>(S), std::vector<int>(static_cast<std::size_t>(N + 1), N));
+        for (int k = N - 1; k >= 0; --k) {
+            const GroupPlan::Column& col = pl.cols[static_cast<std::size_t>(k)];
+            fu[static_cast<std::size_t>(col.pivSlot)][static_cast<std::size_t>(k)] = k;
+            for (int s : col.lSlots) fu[static_cast<std::size_t>(s)][static_cast<std::size_t>(k)] = k;
+            for (const GroupPlan::Check& c : col.checks) fu[static_cast<std::size_t>(c.slot)][static_cast<std::size_t>(k)] = k;
+            for (const GroupPlan::UEntry& u : col.u) {
+                fu[static_cast<std::size_t>(col.pivSlot)][static_cast<std::size_t>(u.j)] = k;
+                for (int s : col.lSlots) fu[static_cast<std::size_t>(s)][static_cast<std::size_t>(u.j)] = k;
+            }
+        }
+        for (int r = 0; r < nStage; ++r)
+            firstUse[static_cast<std::size_t>(r)] = fu[static_cast<std::size_t>(pl.stageRows[static_cast<std::size_t>(r)].s)][static_cast<std::size_t>(pl.stageRows[static_cast<std::size_t>(r)].j)];
     }
+    const int ahead = gopt.stageAhead;
+    auto stageReads = [&](int k) {       // reads issued at the head of column k (k = N: before the substitution)
+        for (int r = 0; r < nStage; ++r) {
+            const int at = ahead < 0 ? 0 : std::max(0, firstUse[static_cast<std::size_t>(r)] - ahead);
+            if (at == k) o << in << "const double sv" << r << " = ST[" << r * G << " + g];\n";
+        }
+    };
+    auto stageAdds = [&](int k) {
+        for (int r = 0; r < nStage; ++r) {
+            const GroupPlan::StageRow& sr = pl.stageRows[static_cast<std::size_t>(r)];
+            const int at = ahead < 0 ? 0 : firstUse[static_cast<std::size_t>(r)];
+            if (at == k) o << in << "a_" << sr.s << "_" << sr.j << " += sv" << r << ";\n";
+        }
+    };
 
     // ---- elimination
     o << in << "double worst = -1.0, tie = -1.0;   // pivot checks of this lane's rows (see the first column)\n";
@@ -443,6 +474,8 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
         const GroupPlan::Column& col = pl.cols[static_cast<std::size_t>(k)];
         const int sk = col.pivSlot, lk = col.pivLane;
         const std::string ak = "a_" + std::to_string(sk) + "_" + std::to_string(k);
+        stageReads(k);
+        stageAdds(k);
         o << in << "// column " << k << ": pivot row = lane " << lk << ", slot " << sk << "\n";
         if (col.zeroPivot || col.contradiction) {
             o << in << "worst = 1.0;   // scheduled pivot is a structural zero / contradicts exact constants\n";
@@ -525,6 +558,8 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
         }
     }
 
+    stageReads(N);
+    stageAdds(N);
     // ---- back substitution, column-wise (solver.hpp:116-128)
     o << in << "// back substitution: x_j is formed in the lane of column j's pivot row, broadcast, and subtracted from the rows\n"
       << in << "// pivoted before it; lane j % 16 keeps it as its solution entry\n";
