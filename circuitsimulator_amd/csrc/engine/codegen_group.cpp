@@ -187,6 +187,8 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
 
     std::ostringstream o;
     o << "#define GRP_WAVE_SIN " << CSIM_WAVE_SIN << "\n#define GRP_WAVE_PULSE " << CSIM_WAVE_PULSE << "\n#define GRP_WAVE_PWL " << CSIM_WAVE_PWL << "\n"
+      << "// outcome of one solve's pivot checks (see the first column of the elimination)\n"
+      << "#define GRP_PIVOTS_BAD (worst > (0x1.0000000000008p+0) || tie >= 0.0 || pmin < " << lit(ir.k.lu_eps) << ")\n"
       << kPrelude << "\n";
 
     // ---- circuit tables
@@ -329,7 +331,10 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     }
 
     for (int r = 0; r < srcRounds; ++r)
-        o << "    const int se" << r << " = grp_src[" << r * G << " + g];       // source evaluated by this lane in round " << r << "\n";
+        o << "    const int se" << r << " = grp_src[" << r * G << " + g];       // source evaluated by this lane in round " << r << " (-1: none)\n"
+          << "    const int sq" << r << " = se" << r << " >= 0 ? se" << r << " : 0;\n"
+          << "    const int ssl" << r << " = grp_slot[sq" << r << "], stb" << r << " = grp_tbase[sq" << r << "], swv" << r << " = grp_wave[sq" << r
+          << "], swn" << r << " = grp_waveN[sq" << r << "];\n";
     for (int r = 0; r < histRounds; ++r)
         o << "    const int hA" << r << " = grp_hA[" << r * G << " + g], hG" << r << " = grp_hG[" << r * G << " + g];\n";
     {
@@ -355,7 +360,11 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
       << "    int smin = (int)(sdone < nSteps ? sdone + 1 : nSteps + 1);\n"
       << "    for (int m = 32; m >= 1; m >>= 1) { const int ot = __shfl_xor(smin, m); smin = ot < smin ? ot : smin; }\n"
       << "    smin = __builtin_amdgcn_readfirstlane(smin);\n"
-      << "    for (long long s = smin; s <= nSteps; ++s) {\n"
+      << "    // output decimation without a 64-bit division per step: phase = gstep % outStride, orow = gstep / outStride\n"
+      << "    int ophase = (int)((stepFirst + smin) % outStride);\n"
+      << "    long long orow = (stepFirst + smin) / outStride;\n"
+      << "    for (long long s = smin; s <= nSteps; ++s, ++ophase) {\n"
+      << "        if (ophase == outStride) { ophase = 0; ++orow; }\n"
       << "        if (!__any(!dead && !viol && sdone < nSteps)) break;\n"
       << "        const bool live = !dead && !viol && sdone + 1 == s;\n"
       << "        const long long gstep = stepFirst + s;\n"
@@ -366,9 +375,8 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
       << "        // per-step terms: sources (sim.hpp:160-162) and history currents (tanalisis.cpp:77,308,337-341)\n";
     for (int r = 0; r < srcRounds; ++r)
         o << "        if (se" << r << " >= 0) {\n"
-          << "            const int sl = grp_slot[se" << r << "], tb = grp_tbase[se" << r << "];\n"
-          << "            const double v = grp_source_tran([&](int i) { return PL[sl + i]; }, grp_wave[se" << r << "], grp_waveN[se" << r << "], tNow, " << lit(K.pi) << ");\n"
-          << "            TS[2 * tb] = v; TS[2 * tb + 1] = -v;\n"
+          << "            const double v = grp_source_tran([&](int i) { return PL[ssl" << r << " + i]; }, swv" << r << ", swn" << r << ", tNow, " << lit(K.pi) << ");\n"
+          << "            TS[2 * stb" << r << "] = v; TS[2 * stb" << r << " + 1] = -v;\n"
           << "        }\n";
     for (int r = 0; r < histRounds; ++r)
         o << "        {\n"
@@ -384,8 +392,13 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     const int slowIters = slowStepIters(K.tran_tol, K.tran_alpha, K.tran_max_iters);
     const std::string in = "            ";
     o << "        bool active = live;\n"
-      << "        int it = 0;\n"
-      << "        for (int iter = 0; iter < " << K.tran_max_iters << "; ++iter) {\n"
+      << "        int it = 0;\n";
+    // The node voltages a lane's MOSFET needs are read one iteration ahead (here for the first one, and right
+    // after the update inside the loop), so that the round trip through the LDS runs under the convergence
+    // bookkeeping instead of in front of the channel evaluation.
+    for (int r = 0; r < mosRounds; ++r)
+        o << "        double vd" << r << " = XS[mD" << r << "], vg" << r << " = XS[mG" << r << "], vs" << r << " = XS[mS" << r << "];\n";
+    o << "        for (int iter = 0; iter < " << K.tran_max_iters << "; ++iter) {\n"
       << "            if (!__any(active)) break;\n";
     // ---- MOSFET evaluation + scatter
     for (int r = 0; r < mosRounds; ++r) {
@@ -393,7 +406,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
         o << in << "{   // MOSFET channel at the iterate (element.cpp:207-274), lane m of the group evaluates MOSFET " << r * G << " + m\n"
           << in << "    double gd, gg, gs, cst;\n"
           << in << "    grp_mos_eval(mp" << R << ", mvth" << R << ", mK" << R << ", mlam" << R << ", " << lit(K.mos_off_gds)
-          << ", XS[mD" << R << "], XS[mG" << R << "], XS[mS" << R << "], gd, gg, gs, cst);\n"
+          << ", vd" << R << ", vg" << R << ", vs" << R << ", gd, gg, gs, cst);\n"
           << in << "    // lanes without a MOSFET write the dummy row (their destinations all point there): no branch\n"
           << in << "    ST[md" << R << "_0] = gd; ST[md" << R << "_1] = gg; ST[md" << R << "_2] = gs; ST[md" << R << "_3] = -cst;\n"
           << in << "    ST[md" << R << "_4] = -gd; ST[md" << R << "_5] = -gg; ST[md" << R << "_6] = -gs; ST[md" << R << "_7] = cst;\n"
@@ -411,10 +424,6 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
         char buf[48];
         std::snprintf(buf, sizeof buf, "(((0x%04x >> g) & 1) ? 1.0 : 0.0)", m.lanes & 0xFFFFu);
         return buf;
-    };
-    auto maskFactor = [&](const GroupPlan::Column::SlotMask& m) -> std::string {
-        const std::string n = maskName(m);
-        return n.empty() ? n : " * " + n;
     };
     auto emitSolve = [&](const GroupPlan& pl, const std::string& in, const std::string& xname) -> bool {
     // ---- assembly: class registers
@@ -468,7 +477,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     };
 
     // ---- elimination
-    o << in << "double worst = -1.0, tie = -1.0;   // pivot checks of this lane's rows (see the first column)\n";
+    o << in << "double worst = 0.0, tie = -1.0, pmin = 1.0;   // pivot checks of this lane's rows (see the first column)\n";
     std::vector<std::string> rinv(static_cast<std::size_t>(N));
     for (int k = 0; k < N; ++k) {
         const GroupPlan::Column& col = pl.cols[static_cast<std::size_t>(k)];
@@ -478,7 +487,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
         stageAdds(k);
         o << in << "// column " << k << ": pivot row = lane " << lk << ", slot " << sk << "\n";
         if (col.zeroPivot || col.contradiction) {
-            o << in << "worst = 1.0;   // scheduled pivot is a structural zero / contradicts exact constants\n";
+            o << in << "worst = 2.0;   // scheduled pivot is a structural zero / contradicts exact constants\n";
             rinv[static_cast<std::size_t>(k)] = "0.0";
             continue;
         }
@@ -489,34 +498,29 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
         } else {
             o << in << "const double pb" << k << " = grp_bc<" << lk << ">(" << ak << ");\n";
             absP = "fabs(pb" + std::to_string(k) + ")";
-            o << in << "worst = fmax(worst, " << lit(K.lu_eps) << " - " << absP << ");\n";
+            o << in << "pmin = fmin(pmin, " << absP << ");\n";          // tiny pivot (solver.hpp:58-61), tested once per solve
         }
-        // Candidates (solver.hpp:48-56).  Every lane is compared: rows that are no candidates hold an exact
-        // zero in column k (structural zero) or are finished rows of the slot being consumed, which the 0/1
-        // factor mk removes.  |pivot| >= |a| must hold for all of them; rows that come BEFORE the scheduled
-        // row in the reference's scan must also differ from it (first maximum wins a tie).  Arithmetic
-        // form, two vector operations per test and nothing scalar: worst = max(|a| - |pivot|) must stay
-        // <= 0, and tie = the same maximum over the rows that must be strictly smaller must stay < 0.
-        // (fmax drops a NaN operand; a NaN anywhere in the solve makes the update norm non-finite, which
-        // is a violation too.)
-        {
-            std::vector<unsigned> strictOf(static_cast<std::size_t>(S), 0u), anyOf(static_cast<std::size_t>(S), 0u);
-            for (const GroupPlan::Check& c : col.checks) {
-                anyOf[static_cast<std::size_t>(c.slot)] |= c.laneMask;
-                if (c.strict) strictOf[static_cast<std::size_t>(c.slot)] |= c.laneMask;
-            }
-            for (int s = 0; s < S; ++s) {
-                if (!anyOf[static_cast<std::size_t>(s)]) continue;
-                const std::string d = "dc" + std::to_string(k) + "_" + std::to_string(s);
-                o << in << "const double " << d << " = fabs(a_" << s << "_" << k << ")" << maskFactor(col.checkMask[static_cast<std::size_t>(s)])
-                  << " - " << absP << ";\n"
-                  << in << "worst = fmax(worst, " << d << ");\n";
-                if (strictOf[static_cast<std::size_t>(s)]) {
-                    char m[16];
-                    std::snprintf(m, sizeof m, "0x%04x", strictOf[static_cast<std::size_t>(s)] & 0xFFFFu);
-                    o << in << "tie = fmax(tie, ((" << m << " >> g) & 1) ? " << d << " : -1.0);\n";
-                }
-            }
+        // Candidates (solver.hpp:48-56): every unfinished row with an entry in column k must not be larger than
+        // the scheduled pivot, and the rows that come BEFORE it in the reference's scan must be strictly smaller
+        // (the first maximum wins a tie).
+        //  - not larger: all those rows get a multiplier f = a / pivot anyway, and |a| <= |pivot| is |f| <= 1: one
+        //    maximum per slot on the multipliers (below), tested once per solve against 1 + 8 ulp -- the slack
+        //    covers the rounding of the refined reciprocal and of the product when |a| == |pivot| exactly (legal
+        //    for rows after the pivot).  A row that exceeds the pivot by less than 2e-15 relative is therefore
+        //    accepted where the reference would swap: the two pivots then agree to 15 digits, and so do the solves.
+        //  - strictly smaller: exact, tie = max(|a| - |pivot|) over exactly those rows must stay < 0.
+        // (fmax/fmin drop a NaN operand; a NaN anywhere in the solve makes the update norm non-finite, which is a
+        // violation too.)
+        std::vector<unsigned> strictOf(static_cast<std::size_t>(S), 0u), anyOf(static_cast<std::size_t>(S), 0u);
+        for (const GroupPlan::Check& c : col.checks) {
+            anyOf[static_cast<std::size_t>(c.slot)] |= c.laneMask;
+            if (c.strict) strictOf[static_cast<std::size_t>(c.slot)] |= c.laneMask;
+        }
+        for (int s = 0; s < S; ++s) {
+            if (!strictOf[static_cast<std::size_t>(s)]) continue;
+            char m[16];
+            std::snprintf(m, sizeof m, "0x%04x", strictOf[static_cast<std::size_t>(s)] & 0xFFFFu);
+            o << in << "tie = fmax(tie, ((" << m << " >> g) & 1) ? fabs(a_" << s << "_" << k << ") - " << absP << " : -1.0);\n";
         }
         if (!col.pivotConst) {
             o << in << "const double r" << k << " = grp_rcp_nr(pb" << k << ");\n";
@@ -539,6 +543,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
                 e = masked ? as + " * (r" + std::to_string(k) + " * " + mf + ")" : as + " * r" + std::to_string(k);
             }
             o << in << "const double f" << k << "_" << s << " = " << e << ";\n";
+            if (anyOf[static_cast<std::size_t>(s)]) o << in << "worst = fmax(worst, fabs(f" << k << "_" << s << "));\n";
         }
         for (const GroupPlan::UEntry& u : col.u) {
             std::string ub;
@@ -589,7 +594,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
         for (std::size_t a = 0; a < plans.size(); ++a) {
             o << in << (a ? "if (__any(active && pv)) " : "") << "{   // schedule " << a << "\n";
             if (!emitSolve(plans[a], in + "    ", "xa")) return std::string();
-            o << in << "    const bool pva = (__ballot(worst > 0.0 || tie >= 0.0) & rowBits) != 0ull;\n";
+            o << in << "    const bool pva = (__ballot(GRP_PIVOTS_BAD) & rowBits) != 0ull;\n";
             for (int s = 0; s < S; ++s) o << in << "    xr" << s << " = pv ? xa" << s << " : xr" << s << ";\n";
             o << in << "    pv = pv && pva;\n"
               << in << "}\n";
@@ -597,27 +602,41 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     }
 
     // ---- damped update, norm, convergence (tanalisis.cpp:360-376)
-    o << in << "double ss = 0.0;\n";
+    // The candidate iterate goes to the LDS before it is known whether the solve stands (that needs the norm and
+    // the pivot checks): a group whose solve does not stand is a violation and restarts the step from XP elsewhere,
+    // and a group that is not iterating keeps its state.
     for (int s = 0; s < S; ++s)
         o << in << "const double xn" << s << " = xo" << s << " + " << lit(K.tran_alpha) << " * (xr" << s << " - xo" << s << ");\n"
-          << in << "{ const double d = xn" << s << " - xo" << s << "; ss += d * d; }\n";
+          << in << "XS[" << s * G << " + g] = active ? xn" << s << " : xo" << s << ";\n";
+    for (int r = 0; r < mosRounds; ++r)
+        o << in << "vd" << r << " = XS[mD" << r << "]; vg" << r << " = XS[mG" << r << "]; vs" << r << " = XS[mS" << r << "];\n";
+    o << in << "__builtin_amdgcn_sched_barrier(0);      // the reads are issued here, not where the compiler would like them\n";
+    o << in << "double ss = 0.0;\n";
+    for (int s = 0; s < S; ++s)
+        o << in << "{ const double d = xn" << s << " - xo" << s << "; ss += d * d; }\n";
     o << in << "ss = grp_sum16(ss);\n"
       << in << "const double err = sqrt(ss);\n"
-      << (multi ? std::string() : in + "const bool pv = (__ballot(worst > 0.0 || tie >= 0.0) & rowBits) != 0ull;\n")
+      << (multi ? std::string() : in + "const bool pv = (__ballot(GRP_PIVOTS_BAD) & rowBits) != 0ull;\n")
       << in << "// branch-free bookkeeping (everything here is uniform within a group of 16 lanes)\n"
       << in << "const bool good = active && !pv && (ss < 1.0e300);      // the solve stands: take the damped update\n"
       << in << "const bool conv = err < " << lit(K.tran_tol) << ";\n"
       << in << "const bool slow = !conv && iter >= " << (slowIters - 1) << ";                 // slow step: plan.hpp slowStepIters\n"
       << in << "viol = viol || (active && !good) || (good && slow);\n"
       << in << "it += good ? 1 : 0;\n";
-    for (int s = 0; s < S; ++s) o << in << "xo" << s << " = good ? xn" << s << " : xo" << s << "; XS[" << s * G << " + g] = xo" << s << ";\n";
+    for (int s = 0; s < S; ++s) o << in << "xo" << s << " = good ? xn" << s << " : xo" << s << ";\n";
+    // the empty asm pins the loads of the next iteration's MOSFET inputs to this side of the loop's back edge (the
+    // compiler otherwise sinks them to the head of the next iteration, in front of the evaluation that needs them)
     o << in << "active = good && !conv && !slow;\n"
+      << in << "__builtin_amdgcn_sched_barrier(0);\n";
+    for (int r = 0; r < mosRounds; ++r)
+        o << in << "asm volatile(\"\" : \"+v\"(vd" << r << "), \"+v\"(vg" << r << "), \"+v\"(vs" << r << "));\n";
+    o
       << "        }\n"      // NR loop
       << "        if (live && !viol) {\n"
       << "            itTotal += it;\n"
       << "            if (stepIters && g == 0) stepIters[(s - 1) * SB + b] = it;\n"
-      << "            if (wave && (gstep % outStride) == 0) {\n"
-      << "                const long long row = gstep / outStride;\n"
+      << "            if (wave && ophase == 0) {\n"
+      << "                const long long row = orow;\n"
       << "                for (int pq = g; pq < nProbe; pq += 16) wave[(row * nProbe + pq) * SB + b] = XS[probeEq[pq]];\n"
       << "            }\n"
       << "            sdone = s;\n"

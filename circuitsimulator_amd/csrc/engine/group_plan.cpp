@@ -12,6 +12,7 @@ namespace {
 struct Kind {
     enum { ZERO, CONST, DYN } k = ZERO;
     double c = 0.0;
+    int lvl = 0;          // what a DYN value depends on: 1 = launch-constant terms, 2 = per-step terms, 3 = the iterate
     bool zero() const { return k == ZERO; }
 };
 
@@ -58,6 +59,23 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
     for (int e = 0; e < ir.n_elems; ++e)
         if (ir.kind[e] == CSIM_L) termIsOne[static_cast<std::size_t>(ap.termBase[static_cast<std::size_t>(e)] + T_L_ONE)] = 1;
 
+    // what each term depends on (see Kind::lvl)
+    std::vector<int> termLevel(static_cast<std::size_t>(ap.nTerms), 1);
+    for (int e = 0; e < ir.n_elems; ++e) {
+        const int tb = ap.termBase[static_cast<std::size_t>(e)];
+        auto set = [&](int off, int lvl) { termLevel[static_cast<std::size_t>(tb + off)] = lvl; };
+        switch (ir.kind[e]) {
+            case CSIM_V: case CSIM_I: set(T_SRC_VAL, 2); break;
+            case CSIM_C: set(T_C_IH, 2); break;
+            case CSIM_L: set(T_L_VH, 2); break;
+            case CSIM_NMOS: case CSIM_PMOS:
+                for (int o = T_M_GD; o <= T_M_CST; ++o) set(o, 3);
+                for (int o = T_M_IHGS; o <= T_M_IHDB; ++o) set(o, 2);
+                break;
+            default: break;
+        }
+    }
+
     // ---- abstract matrix [row][col], col N = rhs
     std::vector<std::vector<Kind>> M(static_cast<std::size_t>(N), std::vector<Kind>(static_cast<std::size_t>(N + 1)));
     auto kindOf = [&](const int32_t* con, int n) {
@@ -65,12 +83,13 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
         if (n == 0) return r;
         bool allConst = true;
         double acc = 0.0;
+        int lvl = 0;
         for (int c = 0; c < n; ++c) {
             const int t = con[c] >> 1;
-            if (!termIsOne[static_cast<std::size_t>(t)]) { allConst = false; break; }
+            if (!termIsOne[static_cast<std::size_t>(t)]) { allConst = false; lvl = std::max(lvl, termLevel[static_cast<std::size_t>(t)]); }
             acc = acc + ((con[c] & 1) ? -1.0 : 1.0);
         }
-        if (!allConst) { r.k = Kind::DYN; return r; }
+        if (!allConst) { r.k = Kind::DYN; r.lvl = lvl; return r; }
         if (acc != 0.0) { r.k = Kind::CONST; r.c = acc; }
         return r;
     };
@@ -181,6 +200,22 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
             if (u.k != Kind::CONST) ++gp.nBcast;
         }
         ++gp.nBcast;                                     // the pivot itself
+        for (const GroupPlan::UEntry& u : col.u)
+            if (!u.isConst) gp.opsByLevel[static_cast<std::size_t>(M[static_cast<std::size_t>(P)][static_cast<std::size_t>(u.j)].lvl)] += 1;   // its broadcast
+        // instructions of this column by what they depend on (slot granularity: one instruction serves the 16
+        // rows of a slot, so it is as variable as its most variable row)
+        auto clsLevel = [&](int s2, int j2) {
+            int l = 0;
+            for (int R2 = 0; R2 < N; ++R2)
+                if (slotOf(R2) == s2 && !M[static_cast<std::size_t>(R2)][static_cast<std::size_t>(j2)].zero())
+                    l = std::max(l, M[static_cast<std::size_t>(R2)][static_cast<std::size_t>(j2)].k == Kind::CONST ? 0 : M[static_cast<std::size_t>(R2)][static_cast<std::size_t>(j2)].lvl);
+            return l;
+        };
+        const int pvL = pv.k == Kind::CONST ? 0 : pv.lvl;
+        if (!col.pivotConst && !col.zeroPivot) gp.opsByLevel[static_cast<std::size_t>(pvL)] += 1 + 5 + 2;     // broadcast, reciprocal, eps test
+        for (const GroupPlan::Check& c : col.checks) gp.opsByLevel[static_cast<std::size_t>(std::max(pvL, clsLevel(c.slot, k)))] += 2;
+        std::vector<int> fLevel(static_cast<std::size_t>(S), 0);
+        for (int s2 = 0; s2 < S; ++s2) fLevel[static_cast<std::size_t>(s2)] = std::max(pvL, clsLevel(s2, k));
         std::vector<char> slotHasL(static_cast<std::size_t>(S), 0);
         for (int i = k + 1; i < N; ++i) {
             const int R = cur[static_cast<std::size_t>(i)];
@@ -190,8 +225,11 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
             Kind f;                                                  // multiplier a / pivot (solver.hpp:71)
             if (a.k == Kind::CONST && pv.k == Kind::CONST) { f.k = Kind::CONST; f.c = a.c * (1.0 / pv.c); }
             else f.k = Kind::DYN;
+            f.lvl = std::max(a.k == Kind::CONST ? 0 : a.lvl, pvL);
             for (const GroupPlan::UEntry& u : col.u) {
                 Kind& t = M[static_cast<std::size_t>(R)][static_cast<std::size_t>(u.j)];
+                const Kind& uk = M[static_cast<std::size_t>(P)][static_cast<std::size_t>(u.j)];
+                const int newLvl = std::max(std::max(f.lvl, uk.k == Kind::CONST ? 0 : uk.lvl), t.k == Kind::DYN ? t.lvl : 0);
                 if (f.k == Kind::CONST && u.isConst && t.k != Kind::DYN) {
                     const double v = (t.k == Kind::CONST ? t.c : 0.0) - f.c * u.c;
                     t.k = v == 0.0 ? Kind::ZERO : Kind::CONST;
@@ -200,12 +238,20 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
                     gp.classLive[static_cast<std::size_t>(slotOf(R))][static_cast<std::size_t>(u.j)] = 1;
                 } else {
                     t.k = Kind::DYN;
+                    t.lvl = newLvl;
                 }
             }
             a = Kind();                                              // below the diagonal: never read again
         }
         for (int s = 0; s < S; ++s)
             if (slotHasL[static_cast<std::size_t>(s)]) {
+                gp.opsByLevel[static_cast<std::size_t>(fLevel[static_cast<std::size_t>(s)])] += 1;                 // multiplier
+                for (const GroupPlan::UEntry& u : col.u) {
+                    const Kind& uk = M[static_cast<std::size_t>(P)][static_cast<std::size_t>(u.j)];
+                    const int ul = uk.k == Kind::CONST ? 0 : uk.lvl;
+                    // after the update loop above clsLevel(s, u.j) already includes this column's contribution
+                    gp.opsByLevel[static_cast<std::size_t>(std::max(std::max(fLevel[static_cast<std::size_t>(s)], ul), clsLevel(s, u.j)))] += 1;
+                }
                 col.lSlots.push_back(s);
                 col.lMask.push_back(col.checkMask[static_cast<std::size_t>(s)]);
                 gp.nMul += col.lMask.back().keepAll ? 1 : 2;

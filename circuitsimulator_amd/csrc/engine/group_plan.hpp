@@ -68,6 +68,9 @@ struct GroupPlan {
         std::vector<UEntry> u;
     };
     std::vector<Column> cols;
+    // elimination instructions (per wave, one solve) by what their operands depend on: [1] terms constant over the
+    // launch, [2] per-step terms (right-hand side), [3] the iterate (MOSFET terms); [0] exact constants
+    std::array<int, 4> opsByLevel{{0, 0, 0, 0}};
     std::vector<std::vector<int>> backSlots; // [j]: slots with rows pivoted before column j whose U(i,j) may be non-zero
     std::vector<std::vector<uint8_t>> classLive;   // [s][j], j <= N: the register class is ever non-zero
 

@@ -103,6 +103,8 @@ static int selftestGroup(const csim_ir* ir, const csim::AssemblyPlan& ap, const 
                 if (e > worst) { worst = e; worstAlt = (int)alt; }
             }
         }
+        std::printf("group plan alt %zu: elimination instructions by dependence: exact constants %d, launch-constant %d, per step %d, per iteration %d\n",
+                    alt, gp.opsByLevel[0], gp.opsByLevel[1], gp.opsByLevel[2], gp.opsByLevel[3]);
         std::printf("group plan alt %zu: N=%d slots=%d classes=%zu staging rows=%zu  per solve (wave instructions): bcast=%d fma=%d mul=%d cmp=%d recip=%d; critical path %d cycles after elimination, %d after substitution\n",
                     alt, gp.N, gp.S, gp.gClasses.size(), gp.stageRows.size(), gp.nBcast, gp.nFma, gp.nMul, gp.nCmp, gp.nRecip,
                     gp.depthElimination, gp.depthSolve);
