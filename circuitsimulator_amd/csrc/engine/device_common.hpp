@@ -26,7 +26,7 @@ namespace csim {
 // device view of the circuit + one mode's gather lists (device pointers)
 struct GenPlan {
     int N, LD, nNodeEq, nElem, P, nTerms, termOne, termGmin;
-    int nnzG, nnzI, hasNonlinear, pad;
+    int nnzG, nnzI, hasNonlinear, nConG, nConI, pad;      // nCon*: lengths of gCon / iCon
     const int32_t *kind, *eq, *branch, *slot, *wave, *waveN, *termBase;
     const int32_t *gPtr, *gPos, *gCon;
     const int32_t *iPtr, *iRow, *iCon;
@@ -58,6 +58,43 @@ __host__ __device__ inline LdsLayout ldsLayout(int N, int LD, int nTerms, int P)
 // instead of letting hipcc contract them into FMAs.  Measured on buffer.sp:
 // worst deviation from the oracle 6.7e-10 -> 4.9e-11 (of a 1e-9 A floor).
 #pragma clang fp contract(off)
+
+// ---- the plan's index arrays, staged in LDS.  Every Newton iteration walks them (element records in the
+// MOSFET pass, gather lists in the assembly) in short dependent chains: pointer, list entry, term.  Only the
+// packed kernels (kernels_packed.hip) stage them -- they run one wave per SIMD whatever their LDS need, and gain
+// 5-8 % (buffer.sp).  The wave-per-instance kernels hide those loads behind their other waves and LOSE
+// throughput when the copies cost occupancy (dbmixer, B = 4096: 6.7e7 -> 4.0e7 NR-iter*inst/s); alone on a SIMD
+// (B = 64) they run at 42 us per iteration either way, so they read the arrays from global memory.
+constexpr size_t kStagedLdsLimit = 64 * 1024;      // a launch whose LDS need with the staged arrays exceeds this reads them from global memory
+__host__ __device__ inline int planLdsInts(const GenPlan& pl)
+{
+    return 10 * pl.nElem + (pl.nnzG + 1) + pl.nnzG + pl.nConG + (pl.nnzI + 1) + pl.nnzI + pl.nConI;
+}
+__device__ __forceinline__ GenPlan plan_in_lds(const GenPlan& pl, int32_t* dst, int lane, int stride)
+{
+    GenPlan o = pl;
+    int32_t* w = dst;
+    auto put = [&](const int32_t* src, int n) {
+        for (int i = lane; i < n; i += stride) w[i] = src[i];
+        const int32_t* at = w;
+        w += n;
+        return at;
+    };
+    o.kind = put(pl.kind, pl.nElem);
+    o.eq = put(pl.eq, 4 * pl.nElem);
+    o.branch = put(pl.branch, pl.nElem);
+    o.slot = put(pl.slot, pl.nElem);
+    o.wave = put(pl.wave, pl.nElem);
+    o.waveN = put(pl.waveN, pl.nElem);
+    o.termBase = put(pl.termBase, pl.nElem);
+    o.gPtr = put(pl.gPtr, pl.nnzG + 1);
+    o.gPos = put(pl.gPos, pl.nnzG);
+    o.gCon = put(pl.gCon, pl.nConG);
+    o.iPtr = put(pl.iPtr, pl.nnzI + 1);
+    o.iRow = put(pl.iRow, pl.nnzI);
+    o.iCon = put(pl.iCon, pl.nConI);
+    return o;                                 // the caller synchronises before the first use
+}
 
 // one wavefront per workgroup: LDS traffic of the wave is ordered by issue, so
 // this is a wait on the LDS queue plus a scheduling fence (the s_barrier of a

@@ -62,6 +62,8 @@ int fillGenPlan(csim_engine* eng, const csim::GatherPlan& g, csim::GenPlan& out)
     out.nnzG = g.nnzG();
     out.nnzI = g.nnzI();
     out.hasNonlinear = ir->has_nonlinear;
+    out.nConG = static_cast<int>(g.gCon.size());
+    out.nConI = static_cast<int>(g.iCon.size());
     out.pad = 0;
     out.kind = eng->dKind; out.eq = eng->dEq; out.branch = eng->dBranch;
     out.slot = eng->dSlot; out.wave = eng->dWave; out.waveN = eng->dWaveN; out.termBase = eng->dTermBase;

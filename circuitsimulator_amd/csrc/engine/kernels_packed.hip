@@ -50,85 +50,140 @@ __device__ __forceinline__ double base_gmin_p(const csim_consts& k, double s)
     return k.gmin_high * (1.0 - s) + k.gmin_low * s;
 }
 
-// lu_solve_wave of device_common.hpp for one group of G lanes (sub-lane g, group q); `on` = this group's
-// solve counts (flags are only raised for such groups).  Returns the solution component of sub-lane g.
-template <int G>
-__device__ __forceinline__ double lu_solve_group(double* Gm, int N, int LD, double eps, int g, int q, bool on,
-                                                 unsigned& flags, int32_t* curPiv)
+// ---- cross-lane plumbing inside one DPP row of 16 lanes (= one instance)
+template <int L> __device__ __forceinline__ double row_bcast(double v)          // lane L of the row -> every lane of it
 {
-    double diag = 1.0;
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + L, 0xF, 0xF, true);      // v_mov_b64_dpp row_newbcast:L
+}
+// the same with the lane in a variable that is a constant once the caller's loop is unrolled
+__device__ __forceinline__ double row_bcast_at(double v, int L)
+{
+    switch (L) {
+        case 0: return row_bcast<0>(v);   case 1: return row_bcast<1>(v);   case 2: return row_bcast<2>(v);   case 3: return row_bcast<3>(v);
+        case 4: return row_bcast<4>(v);   case 5: return row_bcast<5>(v);   case 6: return row_bcast<6>(v);   case 7: return row_bcast<7>(v);
+        case 8: return row_bcast<8>(v);   case 9: return row_bcast<9>(v);   case 10: return row_bcast<10>(v); case 11: return row_bcast<11>(v);
+        case 12: return row_bcast<12>(v); case 13: return row_bcast<13>(v); case 14: return row_bcast<14>(v); default: return row_bcast<15>(v);
+    }
+}
+// maximum over the 16 lanes of a row, in every lane; a NaN operand is ignored (v_max_f64)
+__device__ __forceinline__ double row_shr_keep(double v, int n)                 // lane i <- lane i - n of the row; the first n lanes keep v
+{
+    const long long b = __double_as_longlong(v);
+    long long r;
+    switch (n) {
+        case 1: r = __builtin_amdgcn_update_dpp(b, b, 0x111, 0xF, 0xF, false); break;
+        case 2: r = __builtin_amdgcn_update_dpp(b, b, 0x112, 0xF, 0xF, false); break;
+        case 4: r = __builtin_amdgcn_update_dpp(b, b, 0x114, 0xF, 0xF, false); break;
+        default: r = __builtin_amdgcn_update_dpp(b, b, 0x118, 0xF, 0xF, false); break;
+    }
+    return __longlong_as_double(r);
+}
+__device__ __forceinline__ double row_max16(double v)
+{
+    v = fmax(v, row_shr_keep(v, 1));
+    v = fmax(v, row_shr_keep(v, 2));
+    v = fmax(v, row_shr_keep(v, 4));
+    v = fmax(v, row_shr_keep(v, 8));
+    return row_bcast<15>(v);                                                    // lane 15 holds the maximum of all 16
+}
+
+// Solver::luDecompose + solveLinearSystemLU (solver.hpp:30-131) for one group of 16 lanes with the augmented
+// matrix in REGISTERS: sub-lane g keeps row g, a[j] = column j, a[N] = right-hand side.  Same operations in the
+// same order as the reference -- rows are exchanged for real, so the pivot row of column k always sits in lane k
+// and reaches the others with a compile-time DPP broadcast.  What the LDS version (lu_solve_wave,
+// device_common.hpp) walks one candidate / one non-zero row at a time, a cross-lane round trip each, is one pass
+// here: the pivot is max-reduced over the row of lanes and located with a ballot (the FIRST lane attaining it,
+// solver.hpp:48-56), and every row below the pivot applies its own multiplier at once -- including the rows
+// whose multiplier is zero, as solver.hpp:70-76 does (the LDS version skips those; equal unless the pivot row
+// holds an Inf or NaN).  N is a template parameter: every loop unrolls, every index is a register.
+// `on` = this group's solve counts (flags are only raised for such groups).
+template <int N>
+__device__ __forceinline__ double lu_solve_rows16_n(const double* Gm, int LD, double eps, int g, int q, bool on,
+                                                    unsigned& flags, int32_t* curPiv)
+{
+    double a[N + 1];
+#pragma unroll
+    for (int j = 0; j <= N; ++j) a[j] = (g < N) ? Gm[g * LD + j] : 0.0;
     bool failed = false;
+#pragma unroll
     for (int k = 0; k < N; ++k) {
-        double colv = (g < N) ? Gm[g * LD + k] : 0.0;
-        const double av = fabs(colv);
-        const double akk = grp_get<G>(av, k, q);
+        const double av = fabs(a[k]);
+        const double akk = row_bcast_at(av, k);
         int piv = k;
         double maxAbs = akk;
-        // first row attaining the column maximum (solver.hpp:48-56): ascending walk over the non-zero
-        // candidates below the diagonal; a NaN diagonal keeps pivot = k
-        unsigned cand = grp_mask<G>(g > k && g < N && av > 0.0, q);
-        if (!(akk == akk) || failed) cand = 0u;
-        while (__any(cand != 0u)) {
-            const bool has = cand != 0u;
-            const int i = has ? __ffs((int)cand) - 1 : k;
-            cand &= cand - 1u;
-            const double v = grp_get<G>(av, i, q);
-            if (has && v > maxAbs) { maxAbs = v; piv = i; }
+        if (k + 1 < N) {
+            // candidates below the diagonal; a NaN entry never wins a "val > maxAbs" (:53) and v_max_f64 drops it
+            const double m = row_max16((g > k && g < N) ? av : -1.0);
+            if (akk == akk && m > akk) {                                  // a NaN diagonal keeps pivot = k
+                const unsigned cand = grp_mask<16>(g > k && g < N && av == m, q);
+                maxAbs = m;
+                piv = __ffs((int)cand) - 1;
+            }
         }
         if (!failed && maxAbs < eps) failed = true;                       // :58-61
         const bool live = !failed;
         if (curPiv && g == 0 && live) curPiv[k] = piv;
-        const bool sw = live && piv != k;                                 // swap rows k and piv (columns >= k, RHS)
-        if (sw && g >= k && g <= N) {
-            const double a = Gm[k * LD + g], b = Gm[piv * LD + g];
-            Gm[k * LD + g] = b;
-            Gm[piv * LD + g] = a;
+        const bool sw = live && piv != k;                                 // :64-67 (columns >= k and the RHS matter)
+        if (k + 1 < N && __any(sw)) {
+            const int src = q * 16 + (sw ? (g == k ? piv : (g == piv ? k : g)) : g);
+#pragma unroll
+            for (int j = k; j <= N; ++j) a[j] = __shfl(a[j], src);
         }
-        const double ck = grp_get<G>(colv, k, q), cp = grp_get<G>(colv, piv, q);
-        if (sw && g == k) colv = cp;
-        if (sw && g == piv) colv = ck;
-        wave_sync();
-        const double pivv = grp_get<G>(colv, k, q);
-        if (g == k) diag = pivv;
-        const double rowv = (g > k && g <= N) ? Gm[k * LD + g] : 0.0;
-        const bool active = live && g > k && g < N && colv != 0.0;
-        const double fmine = active ? colv / pivv : 0.0;                  // :71, row = sub-lane
-        unsigned todo = grp_mask<G>(active, q);
-        while (__any(todo != 0u)) {
-            const bool has = todo != 0u;
-            const int i = has ? __ffs((int)todo) - 1 : 0;
-            todo &= todo - 1u;
-            const double f = grp_get<G>(fmine, i, q);
-            if (has && g > k && g <= N) Gm[i * LD + g] -= f * rowv;       // :74 (+ RHS)
+        if (k + 1 < N) {
+            const double pivv = row_bcast_at(a[k], k);
+            double u[N + 1];
+#pragma unroll
+            for (int j = k + 1; j <= N; ++j) u[j] = row_bcast_at(a[j], k);           // the pivot row, to every lane
+            if (live && g > k && g < N) {                                 // :70-76, rows below the pivot
+                const double f = a[k] / pivv;                             // :71
+#pragma unroll
+                for (int j = k + 1; j <= N; ++j) a[j] = a[j] - f * u[j];  // :74 (+ RHS = forward substitution)
+            }
         }
-        wave_sync();
     }
     if (failed) {                                                         // :94-97: zero vector
         if (on) flags |= CSIM_ST_LU_TINY_PIVOT;
         return 0.0;
     }
-    // back substitution (:116-128): row i descending subtracts U(i,j) x(j) for j ascending
-    const double y = (g < N) ? Gm[g * LD + N] : 0.0;
+    // back substitution (:116-128): row i (descending) subtracts U(i,j) x(j) for j ascending.  Every lane runs
+    // the sum on its own row; lane i's is row i's, and its x(i) is broadcast for the rows above.
+    double x[N];
     double xv = 0.0;
+#pragma unroll
     for (int i = N - 1; i >= 0; --i) {
-        const double u = (g > i && g < N) ? Gm[i * LD + g] : 0.0;
-        const double prod = u * xv;
-        unsigned todo = grp_mask<G>(g > i && g < N && prod != 0.0, q);
-        double sum = grp_get<G>(y, i, q);
-        while (__any(todo != 0u)) {
-            const bool has = todo != 0u;
-            const int j = has ? __ffs((int)todo) - 1 : 0;
-            todo &= todo - 1u;
-            const double pj = grp_get<G>(prod, j, q);
-            if (has) sum -= pj;
-        }
-        const double d = grp_get<G>(diag, i, q);
-        double xi;
-        if (fabs(d) < eps) { xi = 0.0; if (on) flags |= CSIM_ST_LU_ZERO_DIAG; }
-        else xi = sum / d;
+        double sum = a[N];
+#pragma unroll
+        for (int j = i + 1; j < N; ++j) sum -= a[j] * x[j];               // :119
+        const double d = row_bcast_at(a[i], i);                           // :121 U(i,i)
+        const bool tiny = fabs(d) < eps;
+        const double xi = tiny ? 0.0 : sum / d;                           // :122-126 (lane i's is x(i))
+        if (on && tiny) flags |= CSIM_ST_LU_ZERO_DIAG;
+        x[i] = row_bcast_at(xi, i);
         if (g == i) xv = xi;
     }
     return xv;
+}
+
+__device__ __forceinline__ double lu_solve_rows16(const double* Gm, int N, int LD, double eps, int g, int q, bool on,
+                                                  unsigned& flags, int32_t* curPiv)
+{
+    switch (N) {        // uniform; one body per size, so that the size is a constant inside
+        case 1: return lu_solve_rows16_n<1>(Gm, LD, eps, g, q, on, flags, curPiv);
+        case 2: return lu_solve_rows16_n<2>(Gm, LD, eps, g, q, on, flags, curPiv);
+        case 3: return lu_solve_rows16_n<3>(Gm, LD, eps, g, q, on, flags, curPiv);
+        case 4: return lu_solve_rows16_n<4>(Gm, LD, eps, g, q, on, flags, curPiv);
+        case 5: return lu_solve_rows16_n<5>(Gm, LD, eps, g, q, on, flags, curPiv);
+        case 6: return lu_solve_rows16_n<6>(Gm, LD, eps, g, q, on, flags, curPiv);
+        case 7: return lu_solve_rows16_n<7>(Gm, LD, eps, g, q, on, flags, curPiv);
+        case 8: return lu_solve_rows16_n<8>(Gm, LD, eps, g, q, on, flags, curPiv);
+        case 9: return lu_solve_rows16_n<9>(Gm, LD, eps, g, q, on, flags, curPiv);
+        case 10: return lu_solve_rows16_n<10>(Gm, LD, eps, g, q, on, flags, curPiv);
+        case 11: return lu_solve_rows16_n<11>(Gm, LD, eps, g, q, on, flags, curPiv);
+        case 12: return lu_solve_rows16_n<12>(Gm, LD, eps, g, q, on, flags, curPiv);
+        case 13: return lu_solve_rows16_n<13>(Gm, LD, eps, g, q, on, flags, curPiv);
+        case 14: return lu_solve_rows16_n<14>(Gm, LD, eps, g, q, on, flags, curPiv);
+        default: return lu_solve_rows16_n<15>(Gm, LD, eps, g, q, on, flags, curPiv);
+    }
 }
 
 template <int G> __device__ __forceinline__ bool grp_all_finite(double v, int N, int g, int q)
@@ -163,9 +218,9 @@ __device__ __forceinline__ bool grp_sequence_known(const int32_t* curPiv, const 
 } // namespace
 
 // ------------------------------------------------------------------ DC (K2g packed)
-template <int G>
+template <int G, bool STAGED>
 __global__ void __launch_bounds__(64)
-k_dc_packed(GenPlan pl, const double* __restrict__ params, int B, double* __restrict__ xout,
+k_dc_packed(GenPlan plArg, const double* __restrict__ params, int B, double* __restrict__ xout,
             int32_t* __restrict__ iters, uint32_t* __restrict__ status, const uint8_t* __restrict__ only)
 {
     extern __shared__ double smp[];
@@ -176,8 +231,10 @@ k_dc_packed(GenPlan pl, const double* __restrict__ params, int B, double* __rest
     const int b = exists ? bRaw : B - 1;
     const bool mine = exists && !(only && !only[b]);         // fallback launches touch the flagged instances only
     if (!__any(mine)) return;
-    const int N = pl.N, LD = pl.LD;
-    const LdsLayout L = ldsLayout(N, LD, pl.nTerms, pl.P);
+    const int N = plArg.N, LD = plArg.LD;
+    const LdsLayout L = ldsLayout(N, LD, plArg.nTerms, plArg.P);
+    // one copy of the plan's index arrays for the groups of the wave, behind their private areas
+    const GenPlan pl = STAGED ? plan_in_lds(plArg, reinterpret_cast<int32_t*>(smp + (size_t)IPW * (L.total + 1)), lane, 64) : plArg;
     double* base = smp + (size_t)q * (L.total + 1);
     double* Gm = base + L.G;
     double* T = base + L.T;
@@ -200,7 +257,7 @@ k_dc_packed(GenPlan pl, const double* __restrict__ params, int B, double* __rest
         if (g == 0) T[pl.termGmin] = 0.0;
         wave_sync();
         assemble(pl, T, Gm, g, G);
-        const double xr = lu_solve_group<G>(Gm, N, LD, K.lu_eps, g, q, mine, st, nullptr);
+        const double xr = lu_solve_rows16(Gm, N, LD, K.lu_eps, g, q, mine, st, nullptr);
         if (g < N) xs[g] = xr;
         itTotal = 1;
     } else {
@@ -217,7 +274,7 @@ k_dc_packed(GenPlan pl, const double* __restrict__ params, int B, double* __rest
                 if (g == 0) T[pl.termGmin] = gmin;
                 wave_sync();
                 assemble(pl, T, Gm, g, G);
-                const double xr = lu_solve_group<G>(Gm, N, LD, K.lu_eps, g, q, active, st, nullptr);
+                const double xr = lu_solve_rows16(Gm, N, LD, K.lu_eps, g, q, active, st, nullptr);
                 if (active) ++itTotal;
                 const bool finite = grp_all_finite<G>(xr, N, g, q);
                 // ConvController::update, computed by every group, applied by the active ones
@@ -253,9 +310,9 @@ k_dc_packed(GenPlan pl, const double* __restrict__ params, int B, double* __rest
 }
 
 // ------------------------------------------------------------ transient (K1g packed)
-template <int G>
+template <int G, bool STAGED>
 __global__ void __launch_bounds__(64)
-k_tran_packed(GenPlan pl, const double* __restrict__ params, int B, double dt,
+k_tran_packed(GenPlan plArg, const double* __restrict__ params, int B, double dt,
               long long stepFirst, long long nSteps, const int32_t* __restrict__ probeEq, int nProbe, int outStride,
               double* __restrict__ wave, double* __restrict__ xio, long long* __restrict__ iters,
               uint32_t* __restrict__ status, int32_t* __restrict__ stepIters, const uint8_t* __restrict__ only,
@@ -271,8 +328,10 @@ k_tran_packed(GenPlan pl, const double* __restrict__ params, int B, double dt,
     const bool mine = exists && !(only && !only[b]) && !(done && d0 >= nSteps);
     if (!__any(mine)) return;
     const long long sEnd = done ? (d0 + maxSteps < nSteps ? d0 + maxSteps : nSteps) : nSteps;
-    const int N = pl.N, LD = pl.LD;
-    const LdsLayout L = ldsLayout(N, LD, pl.nTerms, pl.P);
+    const int N = plArg.N, LD = plArg.LD;
+    const LdsLayout L = ldsLayout(N, LD, plArg.nTerms, plArg.P);
+    // one copy of the plan's index arrays for the groups of the wave, behind their private areas
+    const GenPlan pl = STAGED ? plan_in_lds(plArg, reinterpret_cast<int32_t*>(smp + (size_t)IPW * (L.total + 1)), lane, 64) : plArg;
     double* base = smp + (size_t)q * (L.total + 1);
     double* Gm = base + L.G;
     double* T = base + L.T;
@@ -320,7 +379,7 @@ k_tran_packed(GenPlan pl, const double* __restrict__ params, int B, double dt,
             terms_iter_mos(pl, Pv, T, xs, g, G);
             wave_sync();
             assemble(pl, T, Gm, g, G);                                     // :259-356
-            const double xr = lu_solve_group<G>(Gm, N, LD, K.lu_eps, g, q, active, st, curPiv);   // :359
+            const double xr = lu_solve_rows16(Gm, N, LD, K.lu_eps, g, q, active, st, curPiv);   // :359
             if (curPiv) {                                                  // uniform: every group compares, the active ones keep the answer
                 const bool known = grp_sequence_known<G>(curPiv, knownAlts, nKnown, N, g, q);
                 if (active && stepKnown) stepKnown = known;
@@ -374,10 +433,13 @@ hipError_t launchDcPacked(const GenPlan& pl, const double* dParams, int B, doubl
 {
     const int G = packedLanesFor(pl.N), ipw = 64 / G;
     const LdsLayout L = ldsLayout(pl.N, pl.LD, pl.nTerms, pl.P);
-    const size_t lds = sizeof(double) * (size_t)(L.total + 1) * ipw;
+    const size_t lds = sizeof(double) * (size_t)(L.total + 1) * ipw, staged = lds + sizeof(int32_t) * (size_t)planLdsInts(pl);
     const dim3 grid((B + ipw - 1) / ipw);
     if (G != 16) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_dc_packed<16>, grid, dim3(64), lds, stream, pl, dParams, B, dX, dIters, dStatus, dOnly);
+    if (staged <= kStagedLdsLimit)
+        hipLaunchKernelGGL((k_dc_packed<16, true>), grid, dim3(64), staged, stream, pl, dParams, B, dX, dIters, dStatus, dOnly);
+    else
+        hipLaunchKernelGGL((k_dc_packed<16, false>), grid, dim3(64), lds, stream, pl, dParams, B, dX, dIters, dStatus, dOnly);
     return hipGetLastError();
 }
 
@@ -388,11 +450,15 @@ hipError_t launchTranPacked(const GenPlan& pl, const double* dParams, int B, dou
 {
     const int G = packedLanesFor(pl.N), ipw = 64 / G;
     const LdsLayout L = ldsLayout(pl.N, pl.LD, pl.nTerms, pl.P);
-    const size_t lds = sizeof(double) * (size_t)(L.total + 1) * ipw;
+    const size_t lds = sizeof(double) * (size_t)(L.total + 1) * ipw, staged = lds + sizeof(int32_t) * (size_t)planLdsInts(pl);
     const dim3 grid((B + ipw - 1) / ipw);
     if (G != 16) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_tran_packed<16>, grid, dim3(64), lds, stream, pl, dParams, B, dt, stepFirst, nSteps, dProbeEq,
-                       nProbe, outStride, dWave, dX, dIters, dStatus, dStepIters, dOnly, dDone, maxSteps, dKnownAlts, nKnown);
+    if (staged <= kStagedLdsLimit)
+        hipLaunchKernelGGL((k_tran_packed<16, true>), grid, dim3(64), staged, stream, pl, dParams, B, dt, stepFirst, nSteps, dProbeEq,
+                           nProbe, outStride, dWave, dX, dIters, dStatus, dStepIters, dOnly, dDone, maxSteps, dKnownAlts, nKnown);
+    else
+        hipLaunchKernelGGL((k_tran_packed<16, false>), grid, dim3(64), lds, stream, pl, dParams, B, dt, stepFirst, nSteps, dProbeEq,
+                           nProbe, outStride, dWave, dX, dIters, dStatus, dStepIters, dOnly, dDone, maxSteps, dKnownAlts, nKnown);
     return hipGetLastError();
 }
 
