@@ -203,9 +203,14 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
     int nHandles = 0;
     auto rd = [](int h) { return "@L" + std::to_string(h) + "@"; };
     auto st = [](int h) { return "@S" + std::to_string(h) + "@"; };
+    // "@F<h>|<expr>@": the factor block's read of a launch constant -- from the tape where the step reads it too
+    // (its first slot), else <expr>.  Recomputing it from params there made hipcc keep the parameter's ADDRESS
+    // from the first read alive across the whole factor block: 631 spilled addresses, a 4.9 KB scratch frame.
+    auto rdF = [](int h, const std::string& expr) { return "@F" + std::to_string(h) + "|" + expr + "@"; };
     // ---- terms.  Launch constants are written to the store once (factor block) and re-read where needed.
     std::vector<LV> termF(static_cast<std::size_t>(ap.nTerms)), termS(static_cast<std::size_t>(ap.nTerms));
     std::ostringstream consts;                            // code that fills the launch constants
+    int nConstStmts = 0;                                  // a scheduling barrier every 16: see the factor block
     std::ostringstream stepCode;                          // per-step source values
     termF[static_cast<std::size_t>(ap.termOne)] = termS[static_cast<std::size_t>(ap.termOne)] = LV::konst(1.0);
     termF[static_cast<std::size_t>(ap.termGmin)] = termS[static_cast<std::size_t>(ap.termGmin)] = LV::konst(K.tran_gmin);
@@ -225,7 +230,8 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
             case CSIM_C: {
                 const int h = nHandles++;
                 consts << "    { const double pk = lin_gc(" << PX(s) << ", dt); " << st(h) << " }\n";
-                termF[static_cast<std::size_t>(tb + T_C_GC)] = LV::dyn("lin_gc(" + PF(s) + ", dt)");
+                if ((++nConstStmts % 16) == 0) consts << "    __builtin_amdgcn_sched_barrier(0);\n";
+                termF[static_cast<std::size_t>(tb + T_C_GC)] = LV::dyn(rdF(h, "lin_gc(" + PF(s) + ", dt)"));
                 // history current -Gc * vPrev (tanalisis.cpp:77), evaluated where the right-hand side needs it:
                 // the substitution runs at the start of the step, when XL still holds the previous state
                 const std::string v = (q[0] >= 0 && q[1] >= 0) ? "(" + X(q[0]) + " - " + X(q[1]) + ")"
@@ -236,7 +242,8 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
             case CSIM_L: {
                 const int h = nHandles++;
                 consts << "    { const double L = " << PX(s) << "; viol = viol || !(L > 0.0); const double pk = L / dt; " << st(h) << " }\n";
-                termF[static_cast<std::size_t>(tb + T_L_REQ)] = LV::dyn("(" + PF(s) + " / dt)");
+                if ((++nConstStmts % 16) == 0) consts << "    __builtin_amdgcn_sched_barrier(0);\n";
+                termF[static_cast<std::size_t>(tb + T_L_REQ)] = LV::dyn(rdF(h, "(" + PF(s) + " / dt)"));
                 termF[static_cast<std::size_t>(tb + T_L_ONE)] = LV::konst(1.0);
                 const int kb = ir.branch_eq[e];
                 termS[static_cast<std::size_t>(tb + T_L_VH)] = LV::dyn("(-" + rd(h) + " * " + X((kb >= 0 && kb < N) ? kb : -1) + ")");
@@ -299,7 +306,7 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
         // straight-line blocks and spills what it hoisted (16 KB of scratch per lane, measured)
         if ((k % 2) == 0) gf.out << gf.ind << "__builtin_amdgcn_sched_barrier(0);\n";
         if (pv.zero()) {
-            gf.out << gf.ind << "pvF = true;   // scheduled pivot is a structural zero\n";
+            gf.out << gf.ind << "pvF = 1;   // scheduled pivot is a structural zero\n";
         } else {
             // first row attaining the column maximum (solver.hpp:48-56), >= 1e-15 (:58-61)
             const std::string absP = pv.kind == LV::CONST ? lit(std::fabs(pv.c)) : "fabs(" + pv.e + ")";
@@ -318,13 +325,16 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
                 std::string& m = (i < p) ? mb : ma;
                 m = m.empty() ? absI : "fmax(" + m + ", " + absI + ")";
             }
-            if (contradiction) gf.out << gf.ind << "pvF = true;\n";
+            if (contradiction) gf.out << gf.ind << "pvF = 1;\n";
             else {
                 std::string e;
                 if (pv.kind == LV::DYN) e = ma.empty() ? "(" + absP + " >= " + lit(K.lu_eps) + ")" : "(" + absP + " >= fmax(" + ma + ", " + lit(K.lu_eps) + "))";
                 else if (!ma.empty()) e = "(" + absP + " >= " + ma + ")";
                 if (!mb.empty()) e += std::string(e.empty() ? "" : " & ") + "(" + absP + " > " + mb + ")";
-                if (!e.empty()) gf.out << gf.ind << "pvF |= !(" << e << ");\n";
+                // The flag is an int that an empty asm "uses" after every test: left as a bool that only the end of
+                // the block reads, the compiler sinks all 257 tests there and keeps their operands alive until then
+                // (528 spilled doubles, most of a 4.2 KB scratch frame).
+                if (!e.empty()) gf.out << gf.ind << "pvF |= (" << e << ") ? 0 : 1; asm volatile(\"\" : \"+v\"(pvF));\n";
             }
         }
         if (p != k) { std::swap(M[static_cast<std::size_t>(p)], M[static_cast<std::size_t>(k)]); std::swap(pend[static_cast<std::size_t>(p)], pend[static_cast<std::size_t>(k)]); }
@@ -405,7 +415,7 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
     }
 
     // ---- number the tape in the order of the per-step block's reads
-    std::string stepText = gs.out.str(), factorText = consts.str() + "    // factorisation, once per launch: G does not depend on the iterate or on time\n    bool pvF = false;\n" + gf.out.str();
+    std::string stepText = gs.out.str(), factorText = consts.str() + "    // factorisation, once per launch: G does not depend on the iterate or on time\n    int pvF = 0;\n" + gf.out.str();
     std::vector<std::vector<int>> uses(static_cast<std::size_t>(nHandles));
     int nTape = 0;
     {
@@ -430,6 +440,19 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
             const int h = std::atoi(factorText.substr(a + 2, b - a - 2).c_str());
             outText += factorText.substr(i, a - i);
             for (int n : uses[static_cast<std::size_t>(h)]) outText += "TW(" + std::to_string(n) + ") = pk; ";
+            i = b + 1;
+        }
+        factorText = outText;
+        outText.clear();
+        i = 0;
+        while (i < factorText.size()) {
+            const std::size_t a = factorText.find("@F", i);
+            if (a == std::string::npos) { outText += factorText.substr(i); break; }
+            const std::size_t bar = factorText.find('|', a + 2), b = factorText.find('@', bar + 1);
+            const int h = std::atoi(factorText.substr(a + 2, bar - a - 2).c_str());
+            outText += factorText.substr(i, a - i);
+            if (!uses[static_cast<std::size_t>(h)].empty()) outText += "TF(" + std::to_string(uses[static_cast<std::size_t>(h)][0]) + ")";
+            else outText += factorText.substr(bar + 1, b - bar - 1);
             i = b + 1;
         }
         factorText = outText;
@@ -512,13 +535,15 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
       << "    double* const tapeW = work + ((long long)blockIdx.x * " << nTape << ") * " << LPW << " + lane;\n"
       << "#define TW(n) tapeW[(n) * " << LPW << "]\n"
       << "#define TP(n) tapeR[(n) * " << LPW << "]\n"
+      << "#define TF(n) tapeF[(n) * " << LPW << "]\n"
       << "    bool viol = false;\n"
       << "    const long long vo0 = splitFlag ? 1LL : 0LL;       // always 0, opaque\n"
+      << "    const double* const tapeF = tapeW + vo0;           // the factor block reads launch constants back from the tape\n"
       << "    {\n        const double* xin = xio + bb;\n#pragma unroll 1\n"
       << "        for (int i = 0; i < " << N << "; ++i, xin += SB) XL(i) = *xin;\n    }\n"
       << "    // launch constants (tanalisis.cpp:65-67,296) and the factors -> the tape\n"
       << factorText
-      << "    viol = viol || pvF;\n"
+      << "    viol = viol || pvF != 0;\n"
       << "    unsigned st = inb ? status[bb] : 0u;\n"
       << "    bool dead = !inb || (st & ST_TRAN_NONFINITE) != 0u;\n"
       << "    long long itTotal = 0;\n"
