@@ -25,9 +25,9 @@ hipError_t launchLuFactor(int n, int B, const double* dA, double* dLU, int32_t* 
                           double eps, hipStream_t stream);
 size_t generalLdsBytes(const GenPlan& pl);
 
-// the same kernels with 4 instances per wavefront for N <= 15 (kernels_packed.hip); the launchers above
-// use them whenever no pivot log is asked for
-int packedLanesFor(int N);
+// the same kernels with 4 instances per wavefront and the matrix in registers for N <= 32 (kernels_packed.hip);
+// the launchers above use them whenever no pivot log is asked for
+int packedLanesFor(const GenPlan& pl);
 hipError_t launchDcPacked(const GenPlan& pl, const double* dParams, int B, double* dX, int32_t* dIters,
                           uint32_t* dStatus, hipStream_t stream, const uint8_t* dOnly);
 hipError_t launchTranPacked(const GenPlan& pl, const double* dParams, int B, double dt, long long stepFirst,

@@ -279,7 +279,7 @@ hipError_t launchDcGeneral(const GenPlan& pl, const double* dParams, int B, doub
                            int32_t* dPivLog, int pivInstance)
 {
     // small circuits: several instances per wavefront (kernels_packed.hip); the planner keeps the wave per instance
-    if (!dPivLog && packedLanesFor(pl.N) < 64) return launchDcPacked(pl, dParams, B, dX, dIters, dStatus, stream, dOnly);
+    if (!dPivLog && packedLanesFor(pl) < 64) return launchDcPacked(pl, dParams, B, dX, dIters, dStatus, stream, dOnly);
     const LdsLayout L = ldsLayout(pl.N, pl.LD, pl.nTerms, pl.P);
     const size_t lds = sizeof(double) * (size_t)L.total;
     hipLaunchKernelGGL(k_dc_general, dim3(B), dim3(64), lds, stream, pl, dParams, B, dX, dIters, dStatus, dOnly,
@@ -294,7 +294,7 @@ hipError_t launchTranGeneral(const GenPlan& pl, const double* dParams, int B, do
                              hipStream_t stream, int32_t* dPivLog, int pivInstance, int32_t* dDone, int maxSteps,
                              const int32_t* dKnownAlts, int nKnown)
 {
-    if (!dPivLog && packedLanesFor(pl.N) < 64)
+    if (!dPivLog && packedLanesFor(pl) < 64)
         return launchTranPacked(pl, dParams, B, dt, stepFirst, nSteps, dProbeEq, nProbe, outStride, dWave, dX, dIters, dStatus,
                                 dStepIters, dOnly, stream, dDone, maxSteps, dKnownAlts, nKnown);
     const LdsLayout L = ldsLayout(pl.N, pl.LD, pl.nTerms, pl.P);

@@ -1,4 +1,4 @@
-// dev test (GPU box): lu_solve_rows16 of kernels_packed.hip against a plain host LU on random small systems.
+// dev test (GPU box): the register LU of kernels_packed.hip against a plain host LU on random small systems.
 // hipcc --offload-arch=gfx950 -O3 -I include -I circuitsimulator_amd/csrc/engine -I circuitsimulator_amd/csrc/api lu16_test.hip
 #include "../../../circuitsimulator_amd/csrc/engine/kernels_packed.hip"
 #include <cstdio>
@@ -8,19 +8,33 @@
 #include <cstdlib>
 
 namespace csim {
+template <int S>
 __global__ void k_test(const double* A, int N, int nSys, double* X, unsigned* F, int* P)
 {
-    __shared__ double sm[4 * 16 * 17];
-    __shared__ int pv[4 * 16];
+    __shared__ double gs[4][32 * 32 + 1];
+    __shared__ double rs[4][32];
+    __shared__ int rowMap[32 * 33];
+    __shared__ int pv[4 * 32];
     const int g = threadIdx.x % 16, q = threadIdx.x / 16;
     const int sys = blockIdx.x * 4 + q;
     const int LD = N + 1;
-    double* Gm = sm + q * 16 * 17;
-    if (sys < nSys) for (int i = g; i < N * LD; i += 16) Gm[i] = A[(size_t)sys * N * LD + i];
+    for (int i = threadIdx.x; i < N * LD; i += 64) rowMap[i] = (i % LD < N) ? (i / LD) * N + i % LD : N * N;
+    if (sys < nSys) {
+        for (int i = g; i < N * N; i += 16) gs[q][i] = A[(size_t)sys * N * LD + (i / N) * LD + i % N];
+        for (int i = g; i < N; i += 16) rs[q][i] = A[(size_t)sys * N * LD + i * LD + N];
+    } else {
+        for (int i = g; i < N * N; i += 16) gs[q][i] = (i / N == i % N) ? 1.0 : 0.0;
+        for (int i = g; i < N; i += 16) rs[q][i] = 0.0;
+    }
+    if (g == 0) gs[q][N * N] = 0.0;
     __syncthreads();
     unsigned fl = 0;
-    const double x = lu_solve_rows16(Gm, N, LD, 1e-15, g, q, true, fl, pv + q * 16);
-    if (sys < nSys && g < N) { X[(size_t)sys * N + g] = x; P[(size_t)sys * N + g] = pv[q * 16 + g]; }
+    double x[S];
+    lu_solve_dispatch(gs[q], rs[q], rowMap, N * N, N, LD, 1e-15, g, q, true, fl, pv + q * 32, x);
+    __syncthreads();
+    if (sys < nSys)
+        for (int s = 0; s < S; ++s)
+            if (16 * s + g < N) { X[(size_t)sys * N + 16 * s + g] = x[s]; P[(size_t)sys * N + 16 * s + g] = pv[q * 32 + 16 * s + g]; }
     if (sys < nSys && g == 0) F[sys] = fl;
 }
 }
@@ -49,7 +63,7 @@ static bool hostSolve(int n, const double* Ab, double* x, int* piv)
 int main()
 {
     int bad = 0;
-    for (int N : {1, 2, 5, 13, 15}) {
+    for (int N : {1, 2, 5, 13, 15, 16, 17, 18, 25, 31, 32}) {
         const int nSys = 203, LD = N + 1;
         std::vector<double> A((size_t)nSys * N * LD);
         srand(7 + N);
@@ -58,7 +72,7 @@ int main()
         double *dA, *dX; unsigned* dF; int* dP;
         hipMalloc(&dA, A.size() * 8); hipMalloc(&dX, (size_t)nSys * N * 8); hipMalloc(&dF, nSys * 4); hipMalloc(&dP, (size_t)nSys * N * 4);
         hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
-        csim::k_test<<<(nSys + 3) / 4, 64>>>(dA, N, nSys, dX, dF, dP);
+        if (N <= 16) csim::k_test<1><<<(nSys + 3) / 4, 64>>>(dA, N, nSys, dX, dF, dP); else csim::k_test<2><<<(nSys + 3) / 4, 64>>>(dA, N, nSys, dX, dF, dP);
         std::vector<double> X((size_t)nSys * N); std::vector<unsigned> F(nSys); std::vector<int> P((size_t)nSys * N);
         hipMemcpy(X.data(), dX, X.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(F.data(), dF, nSys * 4, hipMemcpyDeviceToHost);
         hipMemcpy(P.data(), dP, P.size() * 4, hipMemcpyDeviceToHost);
