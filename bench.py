@@ -129,6 +129,8 @@ def main():
     ap.add_argument("--netlist", default=os.path.join(HERE, "tests", "golden", "dbmixer.sp"))
     ap.add_argument("--ladder", type=int, default=0,
                     help="use the synthetic RC ladder with this many nodes instead of --netlist (configs[3]: 256)")
+    ap.add_argument("--no-refine", dest="refine", action="store_false",
+                    help="do not re-specialise the generated kernels with the pivot sequences of flagged instances")
     ap.add_argument("--no-jit", action="store_true", help="do not JIT-specialise a netlist without a prebuilt kernel")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--sigma", type=float, default=0.05)
@@ -187,6 +189,19 @@ def main():
         except Exception as e:                # no hipcc on the box, circuit too large, ...: stay general
             print("bench.py: JIT specialisation unavailable (%s); using the general kernel" % e, file=sys.stderr)
     x, dc_it, status = eng.dc(params)
+    refined = 0
+    if args.refine and eng.tran_kernel == "scheduled" and args.kernel in ("auto", "scheduled") and not args.no_jit:
+        # setup, untimed: one probe step; instances it flags used pivot sequences the generated kernels do not
+        # carry and would finish on the general kernel (a long tail) -- record those sequences and re-specialise
+        xp_, itp_, stp_ = x.clone(), torch.zeros(B, dtype=torch.int64, device=dev), status.clone()
+        eng.tran(params, xp_, tstep, 0, S, itp_, stp_)
+        torch.cuda.synchronize()
+        if int((stp_ & 0x20).ne(0).sum().item()):
+            try:
+                refined = eng.refine_schedules(params, stp_, tstep, n_steps=min(S, 300))
+            except Exception as e:
+                print("bench.py: schedule refinement unavailable (%s)" % e, file=sys.stderr)
+        del xp_, itp_, stp_
     iters = torch.zeros(B, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
@@ -292,7 +307,7 @@ def main():
                 "kernel": kernel,
                 "lanes_per_instance": lanes,
                 "nr_iters_per_step": iters_per_launch,
-                "flagged_instances": n_bad,
+                "flagged_instances": n_bad, "refined_schedules": refined,
             },
             # SURVEY.md 8(d) accounting: the bytes of the DENSE system the reference materialises per NR
             # iteration, 8(N^2+3N), not bytes this kernel moves (it keeps the sparse system on chip; what it

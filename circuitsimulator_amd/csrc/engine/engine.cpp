@@ -1012,7 +1012,7 @@ static int buildAndLoadScheduled(csim_engine* eng, const csim::ScheduleSet& sch)
 int csim_engine_jit_with_schedules(csim_engine* eng, const int32_t* pivot_pos, int32_t n_alts,
                                    const int32_t* dc_pivot_pos, int32_t n_dc_alts)
 {
-    if (!eng || !pivot_pos || n_alts <= 0 || n_alts > 8 || n_dc_alts < 0 || n_dc_alts > 8 || (n_dc_alts > 0 && !dc_pivot_pos)) {
+    if (!eng || !pivot_pos || n_alts <= 0 || n_alts > 16 || n_dc_alts < 0 || n_dc_alts > 8 || (n_dc_alts > 0 && !dc_pivot_pos)) {
         setError("csim_engine_jit_with_schedules: bad argument");
         return CSIM_ERR_ARG;
     }

@@ -289,6 +289,49 @@ class Engine:
             self._h, pos.ctypes.data, pos.shape[0], dpos.ctypes.data if dpos is not None else None,
             dpos.shape[0] if dpos is not None else 0))
 
+    def loaded_schedules(self):
+        """(transient, dc) schedule strings of the generated library in use, in its order ([] / [] without one)."""
+        info = self.sched_info
+        if not info or "schedule=" not in info["text"]:
+            return [], []
+        body = info["text"].split("schedule=", 1)[1].split(" lds_doubles", 1)[0]
+        tran, dc = [], []
+        for item in body.split(";"):
+            item = item.strip()
+            if not item:
+                continue
+            if item.startswith("dc "):
+                dc.append(item[3:].strip())
+            else:
+                tran.append(item)
+        return tran, dc
+
+    def refine_schedules(self, params, status, tstep=None, n_steps=300, max_instances=8, max_new=8):
+        """Instances a run flagged CSIM_ST_SCHED_FALLBACK used pivot sequences the generated kernels do not carry:
+        they then finish on the general kernel, a handful of waves alone on the chip (buffer.sp, 4 096 Monte-Carlo
+        instances at sigma 5 %: 31 instances, 0.8 % of the work, most of the wall time).  This replays up to
+        `max_instances` of them through the planner, appends the sequences it has not seen to the loaded ones and
+        re-specialises (generate + hipcc + load; needs hipcc).  `status` = the status words of that run (tensor or
+        array).  Returns the number of sequences added (0: nothing done).  Results never depend on the list --
+        every factorisation verifies the sequence it uses -- only how many instances stay on the fast kernels."""
+        st = status.cpu().numpy() if hasattr(status, "cpu") else np.asarray(status)
+        flagged = np.nonzero((st & 0x20) != 0)[0]
+        known, known_dc = self.loaded_schedules()
+        if not len(flagged) or not known:
+            return 0
+        have = set(known)
+        new = {}
+        for b in flagged[:max_instances]:
+            alts, _ = self.record_pivot_schedules(params, int(b), tstep, n_steps)
+            for sched, n in alts:
+                if sched not in have:
+                    new[sched] = new.get(sched, 0) + n
+        if not new:
+            return 0
+        added = [s for s, _ in sorted(new.items(), key=lambda kv: -kv[1])][:max_new]
+        self.jit_with_schedules(known + added, known_dc)
+        return len(added)
+
     def record_pivot_schedule(self, params, instance=0, tstep=None, n_steps=200):
         """Planner: pivot row position per column of the first transient factorisation of one
         instance (general kernel), as (schedule string, #factorisations, #with another sequence)."""

@@ -227,7 +227,7 @@ int  csim_engine_jit_scheduled(csim_engine* eng, const double* d_params /*[P][B]
                                double tstep, int64_t plan_steps);
 /* The build half of the above for schedules the caller already has (from the planner
  * entry points below, or from a schedule file): pivot_pos [n_alts][N] transient
- * sequences, most frequent first (1..8); dc_pivot_pos [n_dc_alts][N] sequences of the DC
+ * sequences, most frequent first (1..16); dc_pivot_pos [n_dc_alts][N] sequences of the DC
  * operating point (0..8; 0 = no DC kernel).  Schedules decide speed only: every
  * factorisation re-verifies the sequence it uses.                                   */
 int  csim_engine_jit_with_schedules(csim_engine* eng, const int32_t* pivot_pos, int32_t n_alts,

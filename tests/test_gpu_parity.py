@@ -294,7 +294,7 @@ def test_group_kernel_three_slots_and_two_mosfet_rounds(torch_mod, tmp_path, mon
 
 
 def test_group_kernel_carries_every_recorded_schedule(engines, torch_mod):
-    """buffer.sp at its shipped step alternates between seven pivot schedules.  The group kernel has one
+    """buffer.sp at its shipped step alternates between ten pivot schedules.  The group kernel has one
     solve body per schedule, all over the first schedule's row placement (pivot rows at arbitrary lanes,
     explicit lane masks): it must flag no more instances than the lane-per-instance kernel, and agree with
     the general kernel on every NR count."""
@@ -327,6 +327,41 @@ def test_group_kernel_carries_every_recorded_schedule(engines, torch_mod):
     assert not (r["status"] & 0x27).any()
     o = _orc().tran(nl.ir_ptr, nl.n_unknowns, params.cpu().numpy(), 8, 3e-11, 3e-11 * 1000, want_rows=False)
     assert r["iters"][8] == o["iters"] and rel_err(r["x"][:, 8], o["x_final"]).max() < TOL
+
+
+def test_refining_schedules_from_flagged_instances(torch_mod, tmp_path, monkeypatch):
+    """Instances whose factorisations use pivot sequences the generated kernels do not carry are handed to the
+    general kernel and finish there, a few waves alone on the chip (buffer.sp with the seven sequences of its
+    nominal run: 31 of 4 096 Monte-Carlo instances, most of the wall time).  Engine.refine_schedules replays some
+    of them through the planner, appends what it finds and re-specialises (generator + hipcc + load): fewer
+    instances leave the fast kernels, the results do not move (every factorisation verifies the sequence it uses).
+    Here the kernels are first rebuilt with the three most frequent shipped sequences only."""
+    import shutil
+    from circuitsimulator_amd import Engine, Netlist
+    if not (shutil.which("hipcc") or __import__("os").path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available for the JIT")
+    monkeypatch.setenv("CSIM_JIT_DIR", str(tmp_path / "jit"))
+    nl = Netlist.from_file(netlist_path("buffer.sp"))
+    eng = Engine(nl, 0)
+    shipped, shipped_dc = eng.loaded_schedules()
+    assert len(shipped) == 10 and not shipped_dc
+    eng.jit_with_schedules(shipped[:3])
+    assert eng.loaded_schedules()[0] == shipped[:3]
+    B, steps = 1024, 300
+    params = eng.mc_params(12345, 0.05, 0, B)
+    before = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+    n_before = int(((before["status"] & FALLBACK) != 0).sum())
+    assert n_before > 8
+    added = eng.refine_schedules(params, before["status"], nl.tstep, n_steps=steps)
+    assert added > 0
+    assert eng.loaded_schedules()[0][:3] == shipped[:3] and len(eng.loaded_schedules()[0]) == 3 + added
+    after = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+    n_after = int(((after["status"] & FALLBACK) != 0).sum())
+    assert n_after < n_before // 2, (n_before, n_after)
+    assert np.array_equal(after["step_iters"], before["step_iters"])
+    assert np.array_equal(after["status"] & NOFB, before["status"] & NOFB)
+    assert rel_err(after["x"].T, before["x"].T).max() < TOL
+    eng.close()
 
 
 # --------------------------------------- scheduled (lane-per-instance) kernels
