@@ -189,12 +189,13 @@ def main():
         except Exception as e:                # no hipcc on the box, circuit too large, ...: stay general
             print("bench.py: JIT specialisation unavailable (%s); using the general kernel" % e, file=sys.stderr)
     x, dc_it, status = eng.dc(params)
-    refined = 0
+    refined, probe_steps = 0, 0
     if args.refine and eng.tran_kernel == "scheduled" and args.kernel in ("auto", "scheduled") and not args.no_jit:
         # setup, untimed: one probe step; instances it flags used pivot sequences the generated kernels do not
         # carry and would finish on the general kernel (a long tail) -- record those sequences and re-specialise
         xp_, itp_, stp_ = x.clone(), torch.zeros(B, dtype=torch.int64, device=dev), status.clone()
         eng.tran(params, xp_, tstep, 0, S, itp_, stp_)
+        probe_steps = 1
         torch.cuda.synchronize()
         if int((stp_ & 0x20).ne(0).sum().item()):
             try:
@@ -307,7 +308,7 @@ def main():
                 "kernel": kernel,
                 "lanes_per_instance": lanes,
                 "nr_iters_per_step": iters_per_launch,
-                "flagged_instances": n_bad, "refined_schedules": refined,
+                "flagged_instances": n_bad, "refined_schedules": refined, "setup_probe_steps": probe_steps,
             },
             # SURVEY.md 8(d) accounting: the bytes of the DENSE system the reference materialises per NR
             # iteration, 8(N^2+3N), not bytes this kernel moves (it keeps the sparse system on chip; what it

@@ -26,7 +26,9 @@ def main():
     os.makedirs(dst, exist_ok=True)
     bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
     cmd = open(os.path.join(src, "command.txt")).read().strip()
-    n_steps = bench["steps"] + bench["warmup"]
+    # calls of csim_tran_batch_dev in the traced run: timed + warm-up steps + the untimed set-up probe of
+    # bench.py (one more call of the same length, when it looked for flagged instances)
+    n_steps = bench["steps"] + bench["warmup"] + int(bench["config"].get("setup_probe_steps", 0))
 
     # kernel-trace stats (only this repo's kernels + the total)
     stats = list(csv.DictReader(open(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0])))
