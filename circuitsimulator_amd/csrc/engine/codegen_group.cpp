@@ -542,8 +542,13 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
             } else {
                 e = masked ? as + " * (r" + std::to_string(k) + " * " + mf + ")" : as + " * r" + std::to_string(k);
             }
-            o << in << "const double f" << k << "_" << s << " = " << e << ";\n";
-            if (anyOf[static_cast<std::size_t>(s)]) o << in << "worst = fmax(worst, fabs(f" << k << "_" << s << "));\n";
+            // The NEGATED multiplier: the updates are then a + nf * u, the accumulate form.  v_fmac_f64 is the one FP64
+            // arithmetic instruction with a 4-byte encoding; measured (tools/dev/ubench/valu_lat.hip), a loop of them
+            // issues in 4.2 cycles each against 5.1 for v_fma_f64 (8 bytes), and this change alone took the kernel from
+            // 2.24e9 to 2.35e9.  Same bits as a - f * u.  (The same trick on the back substitution -- negated
+            // reciprocals, negated solution -- converted only 19 more and cost 6 moves + 6 sign flips: 2.29e9, not kept.)
+            o << in << "const double nf" << k << "_" << s << " = -(" << e << ");\n";
+            if (anyOf[static_cast<std::size_t>(s)]) o << in << "worst = fmax(worst, fabs(nf" << k << "_" << s << "));\n";
         }
         for (const GroupPlan::UEntry& u : col.u) {
             std::string ub;
@@ -555,10 +560,10 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
             for (int s : col.lSlots) {
                 const std::string t = "a_" + std::to_string(s) + "_" + std::to_string(u.j);
                 if (!declared[static_cast<std::size_t>(s)][static_cast<std::size_t>(u.j)]) return false;   // fill into a class the plan did not mark
-                const std::string f = "f" + std::to_string(k) + "_" + std::to_string(s);
-                if (u.isConst && u.c == 1.0) o << in << t << " = " << t << " - " << f << ";\n";
-                else if (u.isConst && u.c == -1.0) o << in << t << " = " << t << " + " << f << ";\n";
-                else o << in << t << " = " << t << " - " << f << " * " << ub << ";\n";
+                const std::string f = "nf" + std::to_string(k) + "_" + std::to_string(s);
+                if (u.isConst && u.c == 1.0) o << in << t << " = " << t << " + " << f << ";\n";
+                else if (u.isConst && u.c == -1.0) o << in << t << " = " << t << " - " << f << ";\n";
+                else o << in << t << " = " << t << " + " << f << " * " << ub << ";\n";
             }
         }
     }
