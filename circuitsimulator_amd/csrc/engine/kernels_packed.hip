@@ -113,6 +113,7 @@ inline size_t packedLdsBytes(const GenPlan& pl)
 // assemble(), without the dense matrix)
 __device__ __forceinline__ void gather_nonzeros(const GenPlan& pl, const double* T, double* Gs, double* Rs, int g)
 {
+    // (two non-zeros per trip, to overlap the dependent LDS reads of two sums, was measured slower: 1.25e8 -> 1.20e8)
     for (int n = g; n < pl.nnzG; n += G16) {
         double acc = 0.0;
         for (int c = pl.gPtr[n]; c < pl.gPtr[n + 1]; ++c) {
@@ -150,20 +151,28 @@ __device__ __forceinline__ void lu_column(double (&a)[S][NP + 1], int N, double 
     int piv = K;
     double maxAbs = akk;
     if (K + 1 < NP) {
-        // candidates below the diagonal; a NaN entry never wins a "val > maxAbs" (:53) and v_max_f64 drops it
-        double m = -1.0;
+        // Candidates below the diagonal.  In most columns no row of any of the wave's four instances exceeds its
+        // diagonal (the pivot stays): one comparison and a ballot find that out and skip the reduction (a NaN
+        // diagonal or a NaN candidate compares false, as in the reference's "val > maxAbs", :53).
+        bool bigger = false;
 #pragma unroll
         for (int s = 0; s < S; ++s)
-            if (s >= sk) m = fmax(m, (16 * s + g > K && 16 * s + g < N) ? av[s] : -1.0);
-        m = row_max16(m);
-        if (akk == akk && m > akk) {                                      // a NaN diagonal keeps pivot = K
-            maxAbs = m;
-            piv = -1;                                                     // FIRST row attaining it: lowest slot, lowest lane
+            if (s >= sk) bigger = bigger || (16 * s + g > K && 16 * s + g < N && av[s] > akk);
+        if (__any(bigger)) {
+            double m = -1.0;                                              // v_max_f64 drops a NaN operand
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                if (s < sk) continue;
-                const unsigned cand = grp_mask(16 * s + g > K && 16 * s + g < N && av[s] == m, q);
-                if (piv < 0 && cand != 0u) piv = 16 * s + __ffs((int)cand) - 1;
+            for (int s = 0; s < S; ++s)
+                if (s >= sk) m = fmax(m, (16 * s + g > K && 16 * s + g < N) ? av[s] : -1.0);
+            m = row_max16(m);
+            if (akk == akk && m > akk) {                                  // a NaN diagonal keeps pivot = K
+                maxAbs = m;
+                piv = -1;                                                 // FIRST row attaining it: lowest slot, lowest lane
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    if (s < sk) continue;
+                    const unsigned cand = grp_mask(16 * s + g > K && 16 * s + g < N && av[s] == m, q);
+                    if (piv < 0 && cand != 0u) piv = 16 * s + __ffs((int)cand) - 1;
+                }
             }
         }
     }
