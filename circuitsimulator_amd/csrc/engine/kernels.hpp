@@ -28,6 +28,8 @@ size_t generalLdsBytes(const GenPlan& pl);
 // the same kernels with 4 instances per wavefront and the matrix in registers for N <= 32 (kernels_packed.hip);
 // the launchers above use them whenever no pivot log is asked for
 int packedLanesFor(const GenPlan& pl);
+hipError_t launchLuSolvePacked(int n, int B, const double* dA, const double* dRhs, double* dX, uint32_t* dFlags, double eps,
+                               hipStream_t stream);
 hipError_t launchDcPacked(const GenPlan& pl, const double* dParams, int B, double* dX, int32_t* dIters,
                           uint32_t* dStatus, hipStream_t stream, const uint8_t* dOnly);
 hipError_t launchTranPacked(const GenPlan& pl, const double* dParams, int B, double dt, long long stepFirst,

@@ -307,6 +307,7 @@ hipError_t launchTranGeneral(const GenPlan& pl, const double* dParams, int B, do
 hipError_t launchLuSolve(int n, int B, const double* dA, const double* dRhs, double* dX,
                          uint32_t* dFlags, double eps, hipStream_t stream)
 {
+    if (n <= 32) return launchLuSolvePacked(n, B, dA, dRhs, dX, dFlags, eps, stream);     // four systems per wave, in registers
     const int LD = ldFor(n);
     const size_t lds = sizeof(double) * (size_t)n * (size_t)LD;
     hipLaunchKernelGGL(k_lu_solve, dim3(B), dim3(64), lds, stream, n, LD, B, dA, dRhs, dX, dFlags, eps);
