@@ -580,10 +580,12 @@ def test_lu_known_answers():
 
 
 def test_lu_random_systems_bitwise_equal_to_oracle():
-    """Same pivot rule, same operation order, no FMA contraction -> the same bits."""
+    """Same pivot rule, same operation order, no FMA contraction -> the same bits.  n <= 32 runs on the register
+    LU of the packed general kernels (four systems per wave; 16 / 17 = one / two rows per lane, odd sizes above 16
+    are padded to even), larger n on the LDS version; B = 9 leaves a wave with one system only."""
     from circuitsimulator_amd import lu_solve_batch
     rs = np.random.RandomState(3)
-    for n in (1, 2, 5, 13, 31, 47, 63):
+    for n in (1, 2, 5, 13, 15, 16, 17, 18, 24, 31, 32, 33, 47, 63):
         B = 9
         A = rs.randn(B, n, n)
         A[rs.rand(B, n, n) < 0.6] = 0.0                 # sparse like an MNA matrix
