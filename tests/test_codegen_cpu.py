@@ -47,6 +47,38 @@ def test_shipped_schedule_files_generate_both_kernels(codegen, tmp_path):
     assert src.count("// alternative schedule") >= 6
 
 
+def test_group_plan_self_test_on_the_shipped_schedules(codegen):
+    """The sixteen-lanes-per-instance plan (row placement, lane masks, staging rows, substitution order; for
+    buffer.sp ten schedules over the FIRST one's placement, pivot rows at arbitrary lanes) run through its host
+    interpreter on random term values against a dense elimination with the same pivots: csim_codegen
+    --selftest-group exits 0 when every schedule agrees to 1e-9 and no all-lane candidate test could see a row it
+    must not."""
+    for name in ("buffer", "dbmixer"):
+        p = subprocess.run([codegen, "--selftest-group", netlist_path(name + ".sp"), os.path.join(SCHED, name + ".sched")],
+                           capture_output=True, text=True)
+        assert p.returncode == 0, (name, p.stdout[-400:], p.stderr[-400:])
+        assert "group plan self test: worst relative difference" in p.stdout
+    assert p.stdout.count("group plan alt") >= 1
+
+
+def test_generator_options_are_part_of_the_library_identity(codegen, tmp_path):
+    """--opt key=value changes the emitted code, so it must change the full hash a loaded library is checked
+    against (the topology hash that names the file stays)."""
+    sched = os.path.join(SCHED, "dbmixer.sched")
+    outs = {}
+    for opt in ("stage_ahead=3", "stage_ahead=-1"):
+        out = tmp_path / ("o_" + opt.replace("=", "_").replace("-", "m") + ".hip")
+        p = subprocess.run([codegen, "--opt", opt, netlist_path("dbmixer.sp"), sched, str(out)], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        src = out.read_text()
+        full = src.split("csim_sched_hash(void) { return ")[1].split(";")[0]
+        topo = src.split("csim_sched_topology(void) { return ")[1].split(";")[0]
+        outs[opt] = (full, topo, src.count("const double sv"))
+    a, b = outs["stage_ahead=3"], outs["stage_ahead=-1"]
+    assert a[0] != b[0] and a[1] == b[1]
+    assert a[2] == b[2] > 0                          # the staging rows are read into named values either way
+
+
 def test_schedule_file_syntax(codegen, tmp_path):
     nl = netlist_path("buffer.sp")
     ok = "0:9,1:10,5:11,7:12,8:12   # comment ; with a semicolon\n- ; 0:9\nDC 0:9,1:10\n"
