@@ -119,9 +119,9 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
-    ap.add_argument("--tsteps", type=int, default=4000,
-                    help="time steps per bench step (one csim_tran_batch_dev call); 4000 x (5 + 20) steps = twice the "
-                         "netlist's 50 000-step run (~1.7 s of timed GPU work at B = 4096)")
+    ap.add_argument("--tsteps", type=int, default=6000,
+                    help="time steps per bench step (one csim_tran_batch_dev call); 6000 x (5 + 20) steps = three times "
+                         "the netlist's 50 000-step run (~2 s of timed GPU work at B = 4096 with 20 timed steps)")
     ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 16],
                     help="scheduled kernel: lanes per instance (0 = the engine picks by batch size)")
     ap.add_argument("--dump-gathered", default="",
