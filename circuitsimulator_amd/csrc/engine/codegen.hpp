@@ -66,11 +66,13 @@ struct GeneratorOptions {
     std::vector<int> sweep;      // tuning aid: extra kernels csim_tran_sched_kernel_sweep<k> (see codegen.cpp)
     int stageAhead = 3;          // sixteen-lane kernel: a staging row is read this many columns before the column
                                  // that first needs it (-1: all rows read and added before the elimination)
-    bool set(const std::string& keyval);      // "barrier_every=3", "sweep=0,16,32", "stage_ahead=3"
+    int pipelineMos = 1;         // sixteen-lane kernel: 1 = the MOSFET pass and the staging reads of iteration i+1 run at
+                                 // the end of iteration i, under its convergence bookkeeping; 0 = at the head of i+1
+    bool set(const std::string& keyval);      // "barrier_every=3", "sweep=0,16,32", "stage_ahead=3", "pipeline_mos=0"
 };
 
 // bumped whenever the emitted code or the launcher ABI of a generated library changes
-constexpr int kGeneratorRevision = 19;
+constexpr int kGeneratorRevision = 20;
 
 // identifies (topology, constants, schedule); names the generated library
 uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch);

@@ -398,20 +398,32 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     // bookkeeping instead of in front of the channel evaluation.
     for (int r = 0; r < mosRounds; ++r)
         o << "        double vd" << r << " = XS[mD" << r << "], vg" << r << " = XS[mG" << r << "], vs" << r << " = XS[mS" << r << "];\n";
+    const bool piped = gopt.pipelineMos != 0 && mosRounds > 0 && nStage > 0;
+    // ---- MOSFET evaluation + scatter into the staging rows
+    auto emitMos = [&](const std::string& ind) {
+        for (int r = 0; r < mosRounds; ++r) {
+            const std::string R = std::to_string(r);
+            o << ind << "{   // MOSFET channel at the iterate (element.cpp:207-274), lane m of the group evaluates MOSFET " << r * G << " + m\n"
+              << ind << "    double gd, gg, gs, cst;\n"
+              << ind << "    grp_mos_eval(mp" << R << ", mvth" << R << ", mK" << R << ", mlam" << R << ", " << lit(K.mos_off_gds)
+              << ", vd" << R << ", vg" << R << ", vs" << R << ", gd, gg, gs, cst);\n"
+              << ind << "    // lanes without a MOSFET write the dummy row (their destinations all point there): no branch\n"
+              << ind << "    ST[md" << R << "_0] = gd; ST[md" << R << "_1] = gg; ST[md" << R << "_2] = gs; ST[md" << R << "_3] = -cst;\n"
+              << ind << "    ST[md" << R << "_4] = -gd; ST[md" << R << "_5] = -gg; ST[md" << R << "_6] = -gs; ST[md" << R << "_7] = cst;\n"
+              << ind << "}\n";
+        }
+    };
+    if (piped) {
+        // Software pipeline: the MOSFET pass for iteration i+1 and the reads of its staging rows run at the END of
+        // iteration i (from the candidate iterate, under the convergence bookkeeping); here, once per step, for the
+        // first iteration.  At the head of an iteration the staged values are then already in registers -- the
+        // elimination used to wait there for a write -> read round trip through the LDS.
+        emitMos("        ");
+        for (int r = 0; r < nStage; ++r) o << "        double sv" << r << " = ST[" << r * G << " + g];\n";
+    }
     o << "        for (int iter = 0; iter < " << K.tran_max_iters << "; ++iter) {\n"
       << "            if (!__any(active)) break;\n";
-    // ---- MOSFET evaluation + scatter
-    for (int r = 0; r < mosRounds; ++r) {
-        const std::string R = std::to_string(r);
-        o << in << "{   // MOSFET channel at the iterate (element.cpp:207-274), lane m of the group evaluates MOSFET " << r * G << " + m\n"
-          << in << "    double gd, gg, gs, cst;\n"
-          << in << "    grp_mos_eval(mp" << R << ", mvth" << R << ", mK" << R << ", mlam" << R << ", " << lit(K.mos_off_gds)
-          << ", vd" << R << ", vg" << R << ", vs" << R << ", gd, gg, gs, cst);\n"
-          << in << "    // lanes without a MOSFET write the dummy row (their destinations all point there): no branch\n"
-          << in << "    ST[md" << R << "_0] = gd; ST[md" << R << "_1] = gg; ST[md" << R << "_2] = gs; ST[md" << R << "_3] = -cst;\n"
-          << in << "    ST[md" << R << "_4] = -gd; ST[md" << R << "_5] = -gg; ST[md" << R << "_6] = -gs; ST[md" << R << "_7] = cst;\n"
-          << in << "}\n";
-    }
+    if (!piped) emitMos(in);
     // No fence here or anywhere inside the Newton loop: the LDS executes one wave's instructions in issue
     // order, and the compiler keeps a store and a later load of the same LDS array in program order (they
     // may alias).  A __syncthreads() would add nothing but a scheduling barrier and a full lgkmcnt(0) wait
@@ -465,7 +477,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     auto stageReads = [&](int k) {       // reads issued at the head of column k (k = N: before the substitution)
         for (int r = 0; r < nStage; ++r) {
             const int at = ahead < 0 ? 0 : std::max(0, firstUse[static_cast<std::size_t>(r)] - ahead);
-            if (at == k) o << in << "const double sv" << r << " = ST[" << r * G << " + g];\n";
+            if (at == k && !piped) o << in << "const double sv" << r << " = ST[" << r * G << " + g];\n";
         }
     };
     auto stageAdds = [&](int k) {
@@ -620,8 +632,14 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     for (int s = 0; s < S; ++s)
         o << in << "{ const double d = xn" << s << " - xo" << s << "; ss += d * d; }\n";
     o << in << "ss = grp_sum16(ss);\n"
-      << in << "const double err = sqrt(ss);\n"
-      << (multi ? std::string() : in + "const bool pv = (__ballot(GRP_PIVOTS_BAD) & rowBits) != 0ull;\n")
+      << in << "const double err = sqrt(ss);\n";
+    if (piped) {
+        o << in << "__builtin_amdgcn_sched_barrier(0);      // the norm above ran under the reads of the MOSFET inputs\n";
+        emitMos(in);
+        for (int r = 0; r < nStage; ++r) o << in << "sv" << r << " = ST[" << r * G << " + g];\n";
+        o << in << "__builtin_amdgcn_sched_barrier(0);      // the bookkeeping below runs under the reads of the staging rows\n";
+    }
+    o << (multi ? std::string() : in + "const bool pv = (__ballot(GRP_PIVOTS_BAD) & rowBits) != 0ull;\n")
       << in << "// branch-free bookkeeping (everything here is uniform within a group of 16 lanes)\n"
       << in << "const bool good = active && !pv && (ss < 1.0e300);      // the solve stands: take the damped update\n"
       << in << "const bool conv = err < " << lit(K.tran_tol) << ";\n"
@@ -629,12 +647,20 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
       << in << "viol = viol || (active && !good) || (good && slow);\n"
       << in << "it += good ? 1 : 0;\n";
     for (int s = 0; s < S; ++s) o << in << "xo" << s << " = good ? xn" << s << " : xo" << s << ";\n";
-    // the empty asm pins the loads of the next iteration's MOSFET inputs to this side of the loop's back edge (the
-    // compiler otherwise sinks them to the head of the next iteration, in front of the evaluation that needs them)
+    // the empty asm pins the loads of the next iteration's MOSFET inputs (and staging rows) to this side of the loop's
+    // back edge (the compiler otherwise sinks them to the head of the next iteration, in front of what needs them)
     o << in << "active = good && !conv && !slow;\n"
       << in << "__builtin_amdgcn_sched_barrier(0);\n";
-    for (int r = 0; r < mosRounds; ++r)
-        o << in << "asm volatile(\"\" : \"+v\"(vd" << r << "), \"+v\"(vg" << r << "), \"+v\"(vs" << r << "));\n";
+    if (piped) {
+        for (int r0 = 0; r0 < nStage; r0 += 12) {
+            o << in << "asm volatile(\"\" :";
+            for (int r = r0; r < std::min(nStage, r0 + 12); ++r) o << (r > r0 ? ", " : " ") << "\"+v\"(sv" << r << ")";
+            o << ");\n";
+        }
+    } else {
+        for (int r = 0; r < mosRounds; ++r)
+            o << in << "asm volatile(\"\" : \"+v\"(vd" << r << "), \"+v\"(vg" << r << "), \"+v\"(vs" << r << "));\n";
+    }
     o
       << "        }\n"      // NR loop
       << "        if (live && !viol) {\n"
