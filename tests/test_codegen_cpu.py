@@ -66,17 +66,19 @@ def test_generator_options_are_part_of_the_library_identity(codegen, tmp_path):
     against (the topology hash that names the file stays)."""
     sched = os.path.join(SCHED, "dbmixer.sched")
     outs = {}
-    for opt in ("stage_ahead=3", "stage_ahead=-1"):
-        out = tmp_path / ("o_" + opt.replace("=", "_").replace("-", "m") + ".hip")
+    for opt in ("pipeline_mos=1", "pipeline_mos=0", "stage_ahead=5"):
+        out = tmp_path / ("o_" + opt.replace("=", "_") + ".hip")
         p = subprocess.run([codegen, "--opt", opt, netlist_path("dbmixer.sp"), sched, str(out)], capture_output=True, text=True)
         assert p.returncode == 0, p.stderr
         src = out.read_text()
         full = src.split("csim_sched_hash(void) { return ")[1].split(";")[0]
         topo = src.split("csim_sched_topology(void) { return ")[1].split(";")[0]
-        outs[opt] = (full, topo, src.count("const double sv"))
-    a, b = outs["stage_ahead=3"], outs["stage_ahead=-1"]
-    assert a[0] != b[0] and a[1] == b[1]
-    assert a[2] == b[2] > 0                          # the staging rows are read into named values either way
+        outs[opt] = (full, topo, src)
+    assert len({v[0] for v in outs.values()}) == 3 and len({v[1] for v in outs.values()}) == 1
+    # pipelined: the staging rows are loop-carried values read at the end of an iteration; otherwise named
+    # constants read inside the elimination
+    assert "double sv0 = ST[0 + g];" in outs["pipeline_mos=1"][2] and "const double sv0 = ST[0 + g];" not in outs["pipeline_mos=1"][2]
+    assert "const double sv0 = ST[0 + g];" in outs["pipeline_mos=0"][2]
 
 
 def test_schedule_file_syntax(codegen, tmp_path):
