@@ -982,10 +982,11 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "// Newton-refined reciprocal (v_rcp_f64 + 2 FMA pairs, ~1 ulp) for the pivots\n"
         << "__device__ __forceinline__ double clamp01_cg(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }\n"
         << "__device__ __forceinline__ double rcp_nr(double a)\n{\n"
-        << "    double r = __builtin_amdgcn_rcp(a);\n"
-        << "    r = fma(fma(-a, r, 1.0), r, r);\n"
-        << "    r = fma(fma(-a, r, 1.0), r, r);\n"
-        << "    return r;\n}\n\n";
+        << "    // v_rcp_f64 (2^-24.4 relative) + one cubic step: the correctly rounded reciprocal, as two quadratic\n"
+        << "    // steps give it, in three dependent FMAs instead of four (tools/dev/ubench/rcp_acc.hip)\n"
+        << "    const double r = __builtin_amdgcn_rcp(a);\n"
+        << "    const double e = fma(-a, r, 1.0);\n"
+        << "    return fma(fma(e, e, e), r, r);\n}\n\n";
 
     // linear circuits: factor once per launch, substitute once per step (codegen_linear.cpp).  It replaces
     // the per-iteration kernels below for such circuits (they would re-factor in every Newton pass, and for
