@@ -114,6 +114,7 @@ bool GeneratorOptions::set(const std::string& keyval)
     if (key == "barrier_every") { barrierEvery = std::max(0, std::atoi(val.c_str())); return true; }
     if (key == "stage_ahead") { stageAhead = std::max(-1, std::atoi(val.c_str())); return true; }
     if (key == "pipeline_mos") { pipelineMos = std::atoi(val.c_str()) != 0; return true; }
+    if (key == "group_waves") { groupWavesPerEu = std::max(0, std::atoi(val.c_str())); return true; }
     if (key == "sweep") {
         sweep.clear();
         std::size_t i = 0;
@@ -131,6 +132,7 @@ uint64_t scheduleHash(const csim_ir& ir, const ScheduleSet& set, const Generator
     mix(static_cast<uint64_t>(gopt.barrierEvery) + 1);
     mix(static_cast<uint64_t>(gopt.stageAhead + 2) * 0x100000001b3ull);
     mix(static_cast<uint64_t>(gopt.pipelineMos + 7) * 0x9E3779B1ull);
+    mix(static_cast<uint64_t>(gopt.groupWavesPerEu + 11) * 0x85EBCA6Bull);
     for (int v : gopt.sweep) mix(static_cast<uint64_t>(static_cast<int64_t>(v)) ^ 0x5bd1e995ull);
     for (std::size_t a = 1; a < set.alts.size(); ++a) {
         h ^= 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);

@@ -68,7 +68,8 @@ struct GeneratorOptions {
                                  // that first needs it (-1: all rows read and added before the elimination)
     int pipelineMos = 1;         // sixteen-lane kernel: 1 = the MOSFET pass and the staging reads of iteration i+1 run at
                                  // the end of iteration i, under its convergence bookkeeping; 0 = at the head of i+1
-    bool set(const std::string& keyval);      // "barrier_every=3", "sweep=0,16,32", "stage_ahead=3", "pipeline_mos=0"
+    int groupWavesPerEu = 0;     // sixteen-lane kernel: amdgpu_waves_per_eu(n, n) on the kernel (0 = leave it to the compiler)
+    bool set(const std::string& keyval);      // "barrier_every=3", "sweep=0,16,32", "stage_ahead=3", "pipeline_mos=0", "group_waves=2"
 };
 
 // bumped whenever the emitted code or the launcher ABI of a generated library changes

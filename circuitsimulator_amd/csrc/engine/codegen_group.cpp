@@ -259,7 +259,8 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
              std::string all;
              for (std::size_t a = 0; a < schedules.size(); ++a) all += (a ? " ; " : "") + (schedules[a].str().empty() ? std::string("-") : schedules[a].str());
              return all; }() << "\n"
-      << "extern \"C\" __global__ void __launch_bounds__(64)\n"
+      << "extern \"C\" __global__ void __launch_bounds__(64)"
+      << (gopt.groupWavesPerEu > 0 ? " __attribute__((amdgpu_waves_per_eu(" + std::to_string(gopt.groupWavesPerEu) + ", " + std::to_string(gopt.groupWavesPerEu) + ")))" : std::string()) << "\n"
       << "csim_tran_group_kernel(const double* __restrict__ params, int B, double dt, long long stepFirst,\n"
       << "                       long long nSteps, const int* __restrict__ probeEq, int nProbe, int outStride,\n"
       << "                       double* __restrict__ wave, double* __restrict__ xio, long long* __restrict__ iters,\n"
