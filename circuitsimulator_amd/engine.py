@@ -289,12 +289,12 @@ class Engine:
             self._h, pos.ctypes.data, pos.shape[0], dpos.ctypes.data if dpos is not None else None,
             dpos.shape[0] if dpos is not None else 0))
 
-    def loaded_schedules(self):
-        """(transient, dc) schedule strings of the generated library in use, in its order ([] / [] without one)."""
-        info = self.sched_info
-        if not info or "schedule=" not in info["text"]:
+    @staticmethod
+    def _schedules_in(info_text):
+        """(transient, dc) schedule strings out of a csim_sched_info text"""
+        if not info_text or "schedule=" not in info_text:
             return [], []
-        body = info["text"].split("schedule=", 1)[1].split(" lds_doubles", 1)[0]
+        body = info_text.split("schedule=", 1)[1].split(" lds_doubles", 1)[0]
         tran, dc = [], []
         for item in body.split(";"):
             item = item.strip()
@@ -305,6 +305,11 @@ class Engine:
             else:
                 tran.append(item)
         return tran, dc
+
+    def loaded_schedules(self):
+        """(transient, dc) schedule strings of the generated library in use, in its order ([] / [] without one)."""
+        info = self.sched_info
+        return self._schedules_in(info["text"] if info else "")
 
     def refine_schedules(self, params, status, tstep=None, n_steps=300, max_instances=8, max_new=8):
         """Instances a run flagged CSIM_ST_SCHED_FALLBACK used pivot sequences the generated kernels do not carry:

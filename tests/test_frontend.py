@@ -145,3 +145,21 @@ def test_dc_sweep_table():
     assert nl.dc_sweep_table(2)[0].size == 0                    # not a source
     assert nl.dc_sweep_table(3)[0].size == 0                    # zero step
     assert nl.dc_sweep_table(4)[0].size == 0                    # step of the wrong sign
+
+
+def test_schedule_strings_of_a_generated_library_round_trip():
+    """Engine.refine_schedules rebuilds the kernels from the schedules the loaded library reports plus new ones:
+    the parse of csim_sched_info and the schedule -> pivot-position table must round-trip (host logic, no GPU)."""
+    from circuitsimulator_amd.engine import Engine
+    info = ("buffer.sp N=13 schedule=0:9,1:10,5:11,7:12 ; 0:9,1:10,3:9,5:11,7:12,9:11,11:12 ; - ; dc 0:9,1:10,5:11,7:12,8:12 "
+            "lds_doubles_per_lane=46/46 ops_per_solve: fma=48 mul=40 addsub=81 recip=7 cmp=38")
+    tran, dc = Engine._schedules_in(info)
+    assert tran == ["0:9,1:10,5:11,7:12", "0:9,1:10,3:9,5:11,7:12,9:11,11:12", "-"]
+    assert dc == ["0:9,1:10,5:11,7:12,8:12"]
+    assert Engine._schedules_in("") == ([], []) and Engine._schedules_in("general kernel") == ([], [])
+    pos = Engine._positions(tran, 13)
+    assert pos.shape == (3, 13) and pos.dtype == np.int32
+    assert list(pos[0]) == [9, 10, 2, 3, 4, 11, 6, 12, 8, 9, 10, 11, 12]
+    assert list(pos[2]) == list(range(13))                  # "-" = no swaps
+    back = [",".join("%d:%d" % (k, p) for k, p in enumerate(row) if p != k) or "-" for row in pos]
+    assert back == tran
