@@ -375,7 +375,14 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
       << "        if (live) {";
     for (int s = 0; s < S; ++s) o << " XP[" << s * G << " + g] = xo" << s << ";";
     o << " }\n"
-      << "        // per-step terms: sources (sim.hpp:160-162) and history currents (tanalisis.cpp:77,308,337-341)\n";
+      << "        // per-step terms: sources (sim.hpp:160-162) and history currents (tanalisis.cpp:77,308,337-341).  All LDS reads\n"
+      << "        // of a phase are issued before its first write (the compiler must keep a read behind an earlier write of the\n"
+      << "        // same array): the history operands and the first iteration's MOSFET inputs fly while the sources are\n"
+      << "        // evaluated, the right-hand-side terms in one batch after the writes.\n";
+    for (int r = 0; r < histRounds; ++r)
+        o << "        const double hc" << r << " = TT[hG" << r << " & 0xFFFF], hp" << r << " = XP[hA" << r << " & 0xFF], hq" << r << " = XP[hA" << r << " >> 8];\n";
+    for (int r = 0; r < mosRounds; ++r)
+        o << "        double vd" << r << " = XS[mD" << r << "], vg" << r << " = XS[mG" << r << "], vs" << r << " = XS[mS" << r << "];\n";
     for (int r = 0; r < srcRounds; ++r)
         o << "        if (se" << r << " >= 0) {\n"
           << "            const double v = grp_source_tran([&](int i) { return PL[ssl" << r << " + i]; }, swv" << r << ", swn" << r << ", tNow, " << lit(K.pi) << ");\n"
@@ -383,24 +390,24 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
           << "        }\n";
     for (int r = 0; r < histRounds; ++r)
         o << "        {\n"
-          << "            const double v = -TT[hG" << r << " & 0xFFFF] * (XP[hA" << r << " & 0xFF] - XP[hA" << r << " >> 8]);\n"
+          << "            const double v = -hc" << r << " * (hp" << r << " - hq" << r << ");\n"
           << "            TS[2 * (hG" << r << " >> 16)] = v; TS[2 * (hG" << r << " >> 16) + 1] = -v;\n"
           << "        }\n";
     o << "        // right-hand side without the MOSFET terms, per-step terms summed in the reference's stamping order\n";
+    for (int s = 0; s < S; ++s)
+        for (int t = 0; t < rhsMax[static_cast<std::size_t>(s)]; ++t) o << "        const double rt" << s << "_" << t << " = TS[ri" << s << "_" << t << "];\n";
     for (int s = 0; s < S; ++s) {
         o << "        double cb" << s << " = 0.0;\n";
-        for (int t = 0; t < rhsMax[static_cast<std::size_t>(s)]; ++t) o << "        cb" << s << " += TS[ri" << s << "_" << t << "];\n";
+        for (int t = 0; t < rhsMax[static_cast<std::size_t>(s)]; ++t) o << "        cb" << s << " += rt" << s << "_" << t << ";\n";
     }
 
     const int slowIters = slowStepIters(K.tran_tol, K.tran_alpha, K.tran_max_iters);
     const std::string in = "            ";
     o << "        bool active = live;\n"
       << "        int it = 0;\n";
-    // The node voltages a lane's MOSFET needs are read one iteration ahead (here for the first one, and right
+    // The node voltages a lane's MOSFET needs are read one iteration ahead (above for the first one, and right
     // after the update inside the loop), so that the round trip through the LDS runs under the convergence
     // bookkeeping instead of in front of the channel evaluation.
-    for (int r = 0; r < mosRounds; ++r)
-        o << "        double vd" << r << " = XS[mD" << r << "], vg" << r << " = XS[mG" << r << "], vs" << r << " = XS[mS" << r << "];\n";
     const bool piped = gopt.pipelineMos != 0 && mosRounds > 0 && nStage > 0;
     // ---- MOSFET evaluation + scatter into the staging rows
     auto emitMos = [&](const std::string& ind) {
