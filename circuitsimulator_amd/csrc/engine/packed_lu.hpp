@@ -156,12 +156,11 @@ __device__ __forceinline__ void lu_column(double (&a)[S][NP + 1], int N, double 
     if (sk + 1 < S) {                                                     // the pivot row may sit in the other slot
         const bool swCross = sw && ps != sk;
         if (__any(swCross)) {
-            const int srcA = q * 16 + ((swCross && g == lk) ? pl : g);    // lane lk fetches row piv
-            const int srcB = q * 16 + ((swCross && g == pl) ? lk : g);    // lane pl fetches row K
+            const int srcA = q * 16 + ((swCross && g == lk) ? pl : g);    // lane lk fetches row piv (its lane is run-time)
 #pragma unroll
             for (int j = K; j <= NP; ++j) {
                 const double tA = __shfl(a[S - 1][j], srcA);
-                const double tB = __shfl(a[sk][j], srcB);
+                const double tB = row_bcast<lk>(a[sk][j]);                // row K sits in a lane known here: one DPP move
                 a[sk][j] = (swCross && g == lk) ? tA : a[sk][j];
                 a[S - 1][j] = (swCross && g == pl) ? tB : a[S - 1][j];
             }
