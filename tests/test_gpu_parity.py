@@ -370,6 +370,9 @@ def test_shipped_netlists_have_scheduled_kernels(engines):
     for name in ("buffer", "dbmixer"):
         nl, eng = engines[name]
         assert eng.tran_kernel == "scheduled", name
+        # sixteen lanes per instance up to the measured crossing with the lane-per-instance kernel
+        assert eng.lanes_for_batch(1) == 16 and eng.lanes_for_batch(11264) == 16 and eng.lanes_for_batch(11265) == 1
+        assert len(eng.loaded_schedules()[0]) == {"buffer": 10, "dbmixer": 1}[name]
 
 
 def test_scheduled_equals_general_on_mc_batch(engines, torch_mod):
