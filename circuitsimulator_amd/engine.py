@@ -333,7 +333,10 @@ class Engine:
                     new[sched] = new.get(sched, 0) + n
         if not new:
             return 0
-        added = [s for s, _ in sorted(new.items(), key=lambda kv: -kv[1])][:max_new]
+        room = min(max_new, 16 - len(known))          # csim_engine_jit_with_schedules takes up to 16 transient sequences
+        added = [s for s, _ in sorted(new.items(), key=lambda kv: -kv[1])][:max(0, room)]
+        if not added:
+            return 0
         self.jit_with_schedules(known + added, known_dc)
         return len(added)
 
