@@ -73,7 +73,7 @@ struct GeneratorOptions {
 };
 
 // bumped whenever the emitted code or the launcher ABI of a generated library changes
-constexpr int kGeneratorRevision = 22;
+constexpr int kGeneratorRevision = 23;
 
 // identifies (topology, constants, schedule); names the generated library
 uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch);

@@ -359,8 +359,36 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
       << "    long long itTotal = 0;\n"
       << "    long long sdone = (inb && !dead) ? (long long)done[bb] : nSteps;\n"
       << "    if (stepFirst == 0 && sdone == 0 && wave && inb)\n"
-      << "        for (int pq = g; pq < nProbe; pq += 16) wave[((long long)pq) * SB + b] = XS[probeEq[pq]];\n"
-      << "    int smin = (int)(sdone < nSteps ? sdone + 1 : nSteps + 1);\n"
+      << "        for (int pq = g; pq < nProbe; pq += 16) wave[((long long)pq) * SB + b] = XS[probeEq[pq]];\n";
+    const bool piped = gopt.pipelineMos != 0 && mosRounds > 0 && nStage > 0;
+    // ---- MOSFET evaluation + scatter into the staging rows
+    auto emitMos = [&](const std::string& ind) {
+        for (int r = 0; r < mosRounds; ++r) {
+            const std::string R = std::to_string(r);
+            o << ind << "{   // MOSFET channel at the iterate (element.cpp:207-274), lane m of the group evaluates MOSFET " << r * G << " + m\n"
+              << ind << "    double gd, gg, gs, cst;\n"
+              << ind << "    grp_mos_eval(mp" << R << ", mvth" << R << ", mK" << R << ", mlam" << R << ", " << lit(K.mos_off_gds)
+              << ", vd" << R << ", vg" << R << ", vs" << R << ", gd, gg, gs, cst);\n"
+              << ind << "    // lanes without a MOSFET write the dummy row (their destinations all point there): no branch\n"
+              << ind << "    ST[md" << R << "_0] = gd; ST[md" << R << "_1] = gg; ST[md" << R << "_2] = gs; ST[md" << R << "_3] = -cst;\n"
+              << ind << "    ST[md" << R << "_4] = -gd; ST[md" << R << "_5] = -gg; ST[md" << R << "_6] = -gs; ST[md" << R << "_7] = cst;\n"
+              << ind << "}\n";
+        }
+    };
+    if (piped) {
+        // Software pipeline: the MOSFET pass for iteration i+1 and the reads of its staging rows run at the END of
+        // iteration i (from the candidate iterate, under the convergence bookkeeping), so that at the head of an
+        // iteration the staged values are already in registers -- the elimination used to wait there for a write ->
+        // read round trip through the LDS.  The pass at the end of a step's last iteration saw the state the step
+        // ended with (a group that is not iterating keeps its state in XS, and every pass re-evaluates it from
+        // there), which is what the next step's first iteration needs: only the first step of a launch needs the
+        // pass done for it, here.
+        for (int r = 0; r < mosRounds; ++r)
+            o << "    double vd" << r << " = XS[mD" << r << "], vg" << r << " = XS[mG" << r << "], vs" << r << " = XS[mS" << r << "];\n";
+        emitMos("    ");
+        for (int r = 0; r < nStage; ++r) o << "    double sv" << r << " = ST[" << r * G << " + g];\n";
+    }
+    o << "    int smin = (int)(sdone < nSteps ? sdone + 1 : nSteps + 1);\n"
       << "    for (int m = 32; m >= 1; m >>= 1) { const int ot = __shfl_xor(smin, m); smin = ot < smin ? ot : smin; }\n"
       << "    smin = __builtin_amdgcn_readfirstlane(smin);\n"
       << "    // output decimation without a 64-bit division per step: phase = gstep % outStride, orow = gstep / outStride\n"
@@ -381,8 +409,9 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
       << "        // evaluated, the right-hand-side terms in one batch after the writes.\n";
     for (int r = 0; r < histRounds; ++r)
         o << "        const double hc" << r << " = TT[hG" << r << " & 0xFFFF], hp" << r << " = XP[hA" << r << " & 0xFF], hq" << r << " = XP[hA" << r << " >> 8];\n";
-    for (int r = 0; r < mosRounds; ++r)
-        o << "        double vd" << r << " = XS[mD" << r << "], vg" << r << " = XS[mG" << r << "], vs" << r << " = XS[mS" << r << "];\n";
+    if (!piped)
+        for (int r = 0; r < mosRounds; ++r)
+            o << "        double vd" << r << " = XS[mD" << r << "], vg" << r << " = XS[mG" << r << "], vs" << r << " = XS[mS" << r << "];\n";
     for (int r = 0; r < srcRounds; ++r)
         o << "        if (se" << r << " >= 0) {\n"
           << "            const double v = grp_source_tran([&](int i) { return PL[ssl" << r << " + i]; }, swv" << r << ", swn" << r << ", tNow, " << lit(K.pi) << ");\n"
@@ -405,32 +434,6 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     const std::string in = "            ";
     o << "        bool active = live;\n"
       << "        int it = 0;\n";
-    // The node voltages a lane's MOSFET needs are read one iteration ahead (above for the first one, and right
-    // after the update inside the loop), so that the round trip through the LDS runs under the convergence
-    // bookkeeping instead of in front of the channel evaluation.
-    const bool piped = gopt.pipelineMos != 0 && mosRounds > 0 && nStage > 0;
-    // ---- MOSFET evaluation + scatter into the staging rows
-    auto emitMos = [&](const std::string& ind) {
-        for (int r = 0; r < mosRounds; ++r) {
-            const std::string R = std::to_string(r);
-            o << ind << "{   // MOSFET channel at the iterate (element.cpp:207-274), lane m of the group evaluates MOSFET " << r * G << " + m\n"
-              << ind << "    double gd, gg, gs, cst;\n"
-              << ind << "    grp_mos_eval(mp" << R << ", mvth" << R << ", mK" << R << ", mlam" << R << ", " << lit(K.mos_off_gds)
-              << ", vd" << R << ", vg" << R << ", vs" << R << ", gd, gg, gs, cst);\n"
-              << ind << "    // lanes without a MOSFET write the dummy row (their destinations all point there): no branch\n"
-              << ind << "    ST[md" << R << "_0] = gd; ST[md" << R << "_1] = gg; ST[md" << R << "_2] = gs; ST[md" << R << "_3] = -cst;\n"
-              << ind << "    ST[md" << R << "_4] = -gd; ST[md" << R << "_5] = -gg; ST[md" << R << "_6] = -gs; ST[md" << R << "_7] = cst;\n"
-              << ind << "}\n";
-        }
-    };
-    if (piped) {
-        // Software pipeline: the MOSFET pass for iteration i+1 and the reads of its staging rows run at the END of
-        // iteration i (from the candidate iterate, under the convergence bookkeeping); here, once per step, for the
-        // first iteration.  At the head of an iteration the staged values are then already in registers -- the
-        // elimination used to wait there for a write -> read round trip through the LDS.
-        emitMos("        ");
-        for (int r = 0; r < nStage; ++r) o << "        double sv" << r << " = ST[" << r * G << " + g];\n";
-    }
     o << "        for (int iter = 0; iter < " << K.tran_max_iters << "; ++iter) {\n"
       << "            if (!__any(active)) break;\n";
     if (!piped) emitMos(in);
