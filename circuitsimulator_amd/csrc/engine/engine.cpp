@@ -364,7 +364,7 @@ static int schedVariantFor(const csim_engine* eng, int32_t B)
     if (eng->cfg.lanesPerInstance == 16) return 16;
     if (eng->cfg.lanesPerInstance == 1) return 0;
     // auto: sixteen lanes per instance while the batch is too small to give every SIMD a wave of 64
-    // instances.  Measured on dbmixer (gpurun_out/sw9): 16 lanes 2.37e9 NR-iter*inst/s from B = 4096 up (one
+    // instances.  Measured on dbmixer (gpurun_out/sw9): 16 lanes 2.4-2.5e9 NR-iter*inst/s from B = 4096 up (one
     // wave per SIMD, further instances run as further rounds), one lane 8.6e8 at B = 4096 growing linearly --
     // 1.70e9 at 8192, 2.55e9 at 12 288 -- to 1.25e10 at 65 536: they cross near B = 11 400.  Both kernels carry the
     // same set of pivot schedules.
