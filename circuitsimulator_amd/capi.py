@@ -78,6 +78,7 @@ PROTOTYPES = {
     "csim_engine_jit_scheduled": (C.c_int, [_vp, _vp, _i32, _dbl, _i64]),
     "csim_engine_jit_with_schedules": (C.c_int, [_vp, _vp, _i32, _vp, _i32]),
     "csim_engine_set_option": (C.c_int, [_vp, _cp, _cp]),
+    "csim_engine_stat": (_i64, [_vp, _cp]),
     "csim_record_pivot_schedules": (C.c_int, [_vp, _vp, _i32, _i32, _dbl, _i64, _i32, _vp, _vp, _pi32,
                                               C.POINTER(C.c_int64)]),
     "csim_record_dc_pivot_schedules": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _pi32, C.POINTER(C.c_int64)]),

@@ -115,6 +115,8 @@ bool GeneratorOptions::set(const std::string& keyval)
     if (key == "stage_ahead") { stageAhead = std::max(-1, std::atoi(val.c_str())); return true; }
     if (key == "pipeline_mos") { pipelineMos = std::atoi(val.c_str()) != 0; return true; }
     if (key == "group_waves") { groupWavesPerEu = std::max(0, std::atoi(val.c_str())); return true; }
+    if (key == "near_band") { nearBand = std::max(0.0, std::atof(val.c_str())); return true; }
+    if (key == "near_band_dc") { nearBandDc = std::max(0.0, std::atof(val.c_str())); return true; }
     if (key == "sweep") {
         sweep.clear();
         std::size_t i = 0;
@@ -134,6 +136,8 @@ uint64_t scheduleHash(const csim_ir& ir, const ScheduleSet& set, const Generator
     mix(static_cast<uint64_t>(gopt.pipelineMos + 7) * 0x9E3779B1ull);
     mix(static_cast<uint64_t>(gopt.groupWavesPerEu + 11) * 0x85EBCA6Bull);
     for (int v : gopt.sweep) mix(static_cast<uint64_t>(static_cast<int64_t>(v)) ^ 0x5bd1e995ull);
+    { uint64_t bits; std::memcpy(&bits, &gopt.nearBand, sizeof bits); mix(bits ^ 0xC2B2AE3D27D4EB4Full); }
+    { uint64_t bits; std::memcpy(&bits, &gopt.nearBandDc, sizeof bits); mix(bits ^ 0x165667B19E3779F9ull); }
     for (std::size_t a = 1; a < set.alts.size(); ++a) {
         h ^= 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
         for (int p : set.alts[a].pivotPos) { h ^= static_cast<uint64_t>(p + 1); h *= 1099511628211ull; }
@@ -345,6 +349,8 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
     const int LD = ap.LD;
     const csim_consts& K = ir.k;
     Gen g(ir, ap);
+    // near-threshold guard (codegen.hpp GeneratorOptions::nearBand): the fast kernels only
+    const bool guard = !opt.faithful && (opt.dcMode ? gopt.nearBandDc : gopt.nearBand) > 0.0;
 
     // term -> abstract value.  Exact constants: the global ONE term and the
     // inductor incidence "one" (precondition L > 0 is checked per instance).
@@ -438,14 +444,17 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
     }
 
     if (opt.dcMode) {
+        if (opt.faithful) src << "#pragma clang fp contract(off)\n";
         src << "extern \"C\" __global__ void __launch_bounds__(64)\n"
             << opt.kernelName << "(const double* __restrict__ params, int B, double* __restrict__ xout,\n"
             << "                       int* __restrict__ iters, unsigned* __restrict__ status,\n"
-            << "                       unsigned char* __restrict__ fallback, int* __restrict__ violFlag)\n{\n"
+            << "                       unsigned char* __restrict__ fallback, int* __restrict__ violFlag,\n"
+            << "                       const unsigned char* __restrict__ only)\n{\n"
             << "    __shared__ double lds[@LDS_DOUBLES@ * 64];\n"
             << "    const int lane = threadIdx.x;\n"
             << "    const int b = blockIdx.x * 64 + threadIdx.x;\n"
-            << "    const bool inb = b < B;\n"
+            << "    const bool inb = b < B && (!only || only[b < B ? b : 0] != 0);   // only: the instances this launch replays\n"
+            << "    if (!__any(inb)) return;\n"
             << "    const long long bb = inb ? b : B - 1;      // out-of-range lanes shadow the last instance, never store\n"
             << "    const long long SB = B;\n"
             << "    const bool splitFlag = B < 0;              // never true; opaque to the compiler\n";
@@ -458,7 +467,8 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             << "                       double* __restrict__ wave, double* __restrict__ xio, long long* __restrict__ iters,\n"
             << "                       unsigned* __restrict__ status, int* __restrict__ stepIters,\n"
             << "                       unsigned char* __restrict__ fallback, int* __restrict__ done,\n"
-            << "                       int* __restrict__ violFlag)\n{\n"
+            << "                       int* __restrict__ violFlag, double* __restrict__ nearX, int* __restrict__ nearStep,\n"
+            << "                       int* __restrict__ nearIt, long long* __restrict__ nearItAfter)\n{\n"
             << "    __shared__ double lds[@LDS_DOUBLES@ * 64];\n"
             << "    const int lane = threadIdx.x;\n"
             << "    const int b = blockIdx.x * 64 + threadIdx.x;\n"
@@ -530,6 +540,11 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             << "    // steps of this launch already completed for this instance (hybrid stepping: after a schedule\n"
             << "    // violation the general kernel advances the instance a few steps and hands it back)\n"
             << "    long long sdone = (inb && !dead) ? (long long)done[bb] : nSteps;\n"
+            << (opt.faithful
+                ? "    // hand-over reason 2 (engine.cpp): a near-threshold convergence decision of a fast kernel is redone here with\n"
+                  "    // the reference's arithmetic -- this lane runs ONE time step, then the fast kernel has the instance back\n"
+                  "    const long long lend = (inb && fallback[bb] == 2 && sdone < nSteps) ? sdone + 1 : nSteps;\n"
+                : (guard ? "    int nearS = 0;          // step (of this launch) of the first near-threshold convergence decision; 0 = none\n" : ""))
             << "    if (stepFirst == 0 && sdone == 0 && wave && inb) {\n"
             << "        for (int q = 0; q < nProbe; ++q) wave[((long long)q) * SB + b] = X(probeEq[q]);\n"
             << "    }\n\n"
@@ -540,8 +555,8 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             << "    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(smin, m); smin = o < smin ? o : smin; }\n"
             << "    smin = __builtin_amdgcn_readfirstlane(smin);\n"
             << "    for (long long s = smin; s <= nSteps; ++s) {\n"
-            << "        if (!__any(!dead && !viol && sdone < nSteps)) break;\n"
-            << "        const bool live = !dead && !viol && sdone + 1 == s;\n"
+            << "        if (!__any(!dead && !viol && sdone < " << (opt.faithful ? "lend" : "nSteps") << ")) break;\n"
+            << "        const bool live = !dead && !viol && sdone + 1 == s" << (opt.faithful ? " && sdone < lend" : "") << ";\n"
             << "        const long long gstep = stepFirst + s;\n"
             << "        const double tNow = (double)(int)gstep * dt;\n"
             << "        const long long vo = splitFlag ? s : 0LL;   // always 0, but not to the compiler: keeps per-step re-reads in the loop\n"
@@ -866,6 +881,16 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
           << g.ind << "    if (pv || !(ss < 1.0e300)) { viol = true; active = false; }\n"
           << g.ind << "    else {\n"
           << g.ind << "        ++itTotal;\n";
+        if (guard)
+            // a branch of the controller decided within the rounding noise of this kernel's contracted arithmetic
+            // (:150, :285-296): the bit-faithful DC kernel replays the instance
+            o << g.ind << "        {\n"
+              << g.ind << "            const bool first = (iter == 0 || !isfinite(prevErr));\n"
+              << g.ind << "            const double band = " << lit(gopt.nearBandDc) << " * err;\n"
+              << g.ind << "            if (fabs(err - " << lit(K.dc_tol) << ") <= " << lit(gopt.nearBandDc * K.dc_tol) << " ||\n"
+              << g.ind << "                (!first && (fabs(err - __dmul_rn(prevErr, " << lit(K.slow_ratio) << ")) <= band ||\n"
+              << g.ind << "                            fabs(err - __dmul_rn(prevErr, " << lit(K.fast_ratio) << ")) <= band))) { viol = true; active = false; }\n"
+              << g.ind << "        }\n";
         for (int i = 0; i < N; ++i) o << g.ind << "        X(" << i << ") = xn" << i << ";\n";
         o << g.ind << "        double gnext;\n"
           << g.ind << "        if (iter == 0 || !isfinite(prevErr)) gnext = gb;                                   // :280-282\n"
@@ -880,9 +905,11 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
           // FINAL ramp step ends at the cap the returned operating point is wherever the trajectory
           // stopped, not a fixed point, and only bit-faithful arithmetic reproduces the reference's: the
           // instance is replayed by the general kernel.
+          // (the faithful kernel keeps such a step and flags it, as upstream)
           << g.ind << "        else if (iter == " << (K.dc_max_iters - 1) << ") {\n"
-          << g.ind << "            if (step == " << K.dc_ramp_steps << ") { viol = true; active = false; }\n"
-          << g.ind << "            else st |= ST_DC_NONCONV;\n"
+          << (opt.faithful ? std::string()
+                           : g.ind + "            if (step == " + std::to_string(K.dc_ramp_steps) + ") { viol = true; active = false; }\n" + g.ind + "            else\n")
+          << g.ind << "            st |= ST_DC_NONCONV;\n"
           << g.ind << "        }\n"
           << g.ind << "    }\n"
           << g.ind << "}\n";
@@ -898,7 +925,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             << "            status[b] = st;\n"
             << "        }\n"
             << "    }\n"
-            << "}\n\n";
+            << "}\n" << (opt.faithful ? "#pragma clang fp contract(fast)\n" : "") << "\n";
     } else {
         // ---- damped update, norm in index order, convergence (tanalisis.cpp:360-376)
         std::ostringstream& o = g.out;
@@ -925,6 +952,14 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         o << g.ind << "        if (err < " << lit(K.tran_tol) << ") active = false;\n";
         if (opt.faithful) o << g.ind << "        else if (iter == " << (K.tran_max_iters - 1) << ") st |= ST_TRAN_NONCONV;   // tanalisis.cpp:372-376\n";
         else o << g.ind << "        else if (iter >= " << (slowIters - 1) << ") { viol = true; active = false; }\n";
+        if (guard)
+            // `err < tol` (tanalisis.cpp:369) decided within the rounding noise of this kernel's arithmetic: go on
+            // speculatively; the step's checkpoint is kept at the end of the step and the engine verifies the pass
+            // count with the faithful kernel.  One checkpoint per launch: a second such step stops the lane.
+            o << g.ind << "        if (fabs(err - " << lit(K.tran_tol) << ") <= " << lit(gopt.nearBand * K.tran_tol) << ") {\n"
+              << g.ind << "            if (nearS != 0 && nearS != (int)s) { viol = true; active = false; }\n"
+              << g.ind << "            else nearS = (int)s;\n"
+              << g.ind << "        }\n";
         o
           << g.ind << "    }\n"
           << g.ind << "}\n";
@@ -932,6 +967,13 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         src << g.out.str();
         src << i2 << "}\n"      // NR loop
             << i2 << "if (live && !viol) {\n"
+            << (guard
+                ? i2 + "    if (nearS == (int)s) {     // xio still holds the state at the start of this step: keep it for the verification\n"
+                  + i2 + "        const double* ck = xio + b;\n" + i2 + "        double* nk = nearX + b;\n#pragma unroll 1\n"
+                  + i2 + "        for (int i = 0; i < " + std::to_string(N) + "; ++i, ck += SB, nk += SB) *nk = *ck;\n"
+                  + i2 + "        nearStep[b] = (int)s; nearIt[b] = it; nearItAfter[b] = itTotal;\n"
+                  + i2 + "    }\n"
+                : std::string())
             << i2 << "    itTotal += it;\n"
             << i2 << "    if (stepIters) stepIters[(s - 1) * SB + b] = it;\n"
             << i2 << "    if (wave && !dead && (gstep % outStride) == 0) {\n"
@@ -943,7 +985,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             << i2 << "}\n"
             << "    }\n\n"
             << "    if (inb) {\n"
-            << "        if (viol) { fallback[b] = 1; *violFlag = 1; }   // xio holds the checkpoint of the step that failed\n"
+            << "        if (viol) fallback[b] = 1;   // xio holds the checkpoint of the step that failed\n"
             << "        else {\n";
         src << "            double* xo = xio + b;\n#pragma unroll 1\n"
             << "            for (int i = 0; i < " << N << "; ++i, xo += SB) *xo = X(i);\n"
@@ -951,6 +993,9 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             << "        iters[b] += itTotal;\n"
             << "        status[b] |= st;\n"
             << "        done[b] = (int)sdone;\n"
+            << "        if (sdone < nSteps) violFlag[0] = 1;      // unfinished: the engine goes on with this instance\n"
+            << (opt.faithful ? "        if (!viol && fallback[b] == 2) fallback[b] = 0;   // the one step asked for is done\n" : "")
+            << (guard ? "        if (nearS != 0 && sdone >= nearS) { nearItAfter[b] = itTotal - nearItAfter[b]; violFlag[1] = 1; }   // to be verified\n" : "")
             << "    }\n"
             << "}\n" << (opt.faithful ? "#pragma clang fp contract(fast)\n" : "") << "\n";
 
@@ -981,7 +1026,7 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "#include <hip/hip_runtime.h>\n#include <stdint.h>\n\n"
         << "#define ST_TRAN_NONFINITE 0x0001u\n#define ST_TRAN_NONCONV 0x0002u\n#define ST_DC_NONCONV 0x0008u\n#define ST_SCHED_FAITHFUL 0x0100u\n\n"
         << "#define Q(k) lds[(k) * 64 + lane]\n#define X(i) Q(i)\n#define S(j) Q(" << N << " + (j))\n\n"
-        << "// Newton-refined reciprocal (v_rcp_f64 + 2 FMA pairs, ~1 ulp) for the pivots\n"
+        << "// refined reciprocal for the pivots: v_rcp_f64 + one cubic step (three dependent FMAs)\n"
         << "__device__ __forceinline__ double clamp01_cg(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }\n"
         << "__device__ __forceinline__ double rcp_nr(double a)\n{\n"
         << "    // v_rcp_f64 (2^-24.4 relative) + one cubic step: the correctly rounded reciprocal, as two quadratic\n"
@@ -1046,11 +1091,20 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
 
     // DC operating point with its own recorded schedules (Newton circuits only: a linear circuit's
     // DC is one solve, left to the general kernel)
+    // Two kernels: csim_dc_faithful_kernel performs the reference's operations (no contraction, true divisions),
+    // bit for bit the general kernel's operating points on the recorded sequences -- the engine's default;
+    // csim_dc_sched_kernel is the fast one (contraction, reciprocal pivots, near-threshold guard).
     int ldsDc = -1;
     if (!set.dcAlts.empty() && ir.has_nonlinear) {
         VariantOptions dcOpt{"csim_dc_sched_kernel", false, false, leanBudget > 0 ? leanBudget : 0};
         dcOpt.dcMode = true;
         ldsDc = emitVariant(dcOpt, nullptr);
+        if (ldsDc >= 0) {
+            VariantOptions dcFaith{"csim_dc_faithful_kernel", false, false, leanBudget > 0 ? leanBudget : 0};
+            dcFaith.dcMode = true;
+            dcFaith.faithful = true;
+            if (emitVariant(dcFaith, nullptr) < 0) return std::string();     // cannot happen: same LDS image
+        }
     }
     const bool haveDc = ldsDc >= 0;
 
@@ -1099,22 +1153,39 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         src << "0";
     }
     src << "};\n    *nAlts = " << (haveDc ? set.dcAlts.size() : 0) << ";\n    *n = " << N << ";\n    return table;\n}\n"
+        << "// variant 0 = the faithful kernel, 2 = the fast one; only (or null) = mask of the instances to run;\n"
+        << "// an instance the kernel cannot finish (pivot check, non-finite solve, guarded decision) gets fallback[b] = 1\n"
         << "extern \"C\" int csim_sched_dc_launch(const double* params, int B, double* xout, int* iters, unsigned* status,\n"
-        << "                                    unsigned char* fallback, int* violFlag, void* stream)\n{\n";
+        << "                                    unsigned char* fallback, int* violFlag, const unsigned char* only,\n"
+        << "                                    void* stream, int variant)\n{\n";
     if (haveDc)
         src << "    if (B <= 0) return 0;\n"
-            << "    hipLaunchKernelGGL(csim_dc_sched_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream,\n"
-            << "                       params, B, xout, iters, status, fallback, violFlag);\n"
+            << "    if (variant == 2)\n"
+            << "        hipLaunchKernelGGL(csim_dc_sched_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream,\n"
+            << "                           params, B, xout, iters, status, fallback, violFlag, only);\n"
+            << "    else\n"
+            << "        hipLaunchKernelGGL(csim_dc_faithful_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream,\n"
+            << "                           params, B, xout, iters, status, fallback, violFlag, only);\n"
             << "    return (int)hipGetLastError();\n}\n";
     else
-        src << "    (void)params; (void)B; (void)xout; (void)iters; (void)status; (void)fallback; (void)violFlag; (void)stream;\n    return -1;\n}\n";
+        src << "    (void)params; (void)B; (void)xout; (void)iters; (void)status; (void)fallback; (void)violFlag; (void)only; (void)stream; (void)variant;\n    return -1;\n}\n";
     src << "// variant: 0/1 = lean (measured fastest at every batch size: park-budget sweep in DESIGN.md),\n"
         << "//          2 = rich (tuning aid), 10+k = sweep kernels when generated with CSIM_CG_SWEEP\n"
+        << "// auxiliaries of the hand-over protocol (device pointers; engine_internal.hpp holds the same struct):\n"
+        << "//   fallback[B]  why an instance left a kernel unfinished (1: a check failed / slow step; 2, set by the engine: a\n"
+        << "//                near-threshold decision is to be redone -- the faithful kernel then runs ONE step of it)\n"
+        << "//   done[B]      steps of this launch completed;  flags[2]: [0] some instance is unfinished, [1] some\n"
+        << "//                near-threshold decision awaits verification;  work: factor store of the linear-circuit kernel\n"
+        << "//   nearX[N][B], nearStep[B], nearIt[B], nearItAfter[B]: state at the start of an instance's first near-threshold\n"
+        << "//                step of the launch, that step (1-based), its pass count, passes counted from that step on\n"
+        << "struct csim_sched_aux { unsigned char* fallback; int* done; int* flags; double* work; double* nearX; int* nearStep; int* nearIt; long long* nearItAfter; };\n"
+        << "#define CSIM_AUX_ARGS aux->fallback, aux->done, aux->flags, aux->nearX, aux->nearStep, aux->nearIt, aux->nearItAfter\n"
         << "extern \"C\" int csim_sched_launch(const double* params, int B, double dt, long long stepFirst, long long nSteps,\n"
         << "                                 const int* probeEq, int nProbe, int outStride, double* wave, double* xio,\n"
-        << "                                 long long* iters, unsigned* status, int* stepIters, unsigned char* fallback,\n"
-        << "                                 int* done, int* violFlag, double* work, void* stream, int variant)\n{\n"
+        << "                                 long long* iters, unsigned* status, int* stepIters, const csim_sched_aux* aux,\n"
+        << "                                 void* stream, int variant)\n{\n"
         << "    if (B <= 0) return 0;\n"
+        << "    double* const work = aux->work;\n"
         << "    const unsigned waves = (unsigned)((B + 63) / 64);\n"
         << "    const bool rich = " << (haveRich ? "(variant == 2)" : "false") << ";\n"
         ;
@@ -1123,28 +1194,28 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         src << "    if (work) {   // linear circuit: factor once per launch, substitute once per step\n"
             << "        hipLaunchKernelGGL(csim_tran_linear_kernel, dim3((unsigned)((B + " << linLanes - 1 << ") / " << linLanes << ")), dim3(" << linLanes << "), 0, (hipStream_t)stream,\n"
             << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
-            << "                           stepIters, fallback, done, violFlag, work);\n"
+            << "                           stepIters, aux->fallback, aux->done, aux->flags, work);\n"
             << "        return (int)hipGetLastError();\n    }\n";
     if (haveFaithful)
         src << "    if (variant == 3) {\n"
             << "        hipLaunchKernelGGL(csim_tran_faithful_kernel, dim3(waves), dim3(64), 0, (hipStream_t)stream,\n"
             << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
-            << "                           stepIters, fallback, done, violFlag);\n"
+            << "                           stepIters, CSIM_AUX_ARGS);\n"
             << "        return (int)hipGetLastError();\n    }\n";
     if (haveGroup)
         src << "    if (variant == 16) {\n"
             << "        hipLaunchKernelGGL(csim_tran_group_kernel, dim3((unsigned)((B + 3) / 4)), dim3(64), 0, (hipStream_t)stream,\n"
             << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
-            << "                           stepIters, fallback, done, violFlag);\n"
+            << "                           stepIters, CSIM_AUX_ARGS);\n"
             << "        return (int)hipGetLastError();\n    }\n";
     for (std::size_t k = 0; k < sweep.size(); ++k)
         src << "    if (variant == " << (10 + k) << ") { hipLaunchKernelGGL(csim_tran_sched_kernel_sweep" << k
-            << ", dim3(waves), dim3(64), 0, (hipStream_t)stream, params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status, stepIters, fallback, done, violFlag); return (int)hipGetLastError(); }\n";
+            << ", dim3(waves), dim3(64), 0, (hipStream_t)stream, params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status, stepIters, CSIM_AUX_ARGS); return (int)hipGetLastError(); }\n";
     if (haveRich)
         src << "    if (rich) {\n"
             << "        hipLaunchKernelGGL(csim_tran_sched_kernel_rich, dim3(waves), dim3(64), 0, (hipStream_t)stream,\n"
             << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
-            << "                           stepIters, fallback, done, violFlag);\n"
+            << "                           stepIters, CSIM_AUX_ARGS);\n"
             << "        return (int)hipGetLastError();\n    }\n";
     src << "    (void)rich; (void)waves;\n";
     if (haveLinear)
@@ -1152,7 +1223,7 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     else
         src << "    hipLaunchKernelGGL(csim_tran_sched_kernel, dim3(waves), dim3(64), 0, (hipStream_t)stream,\n"
             << "                       params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
-            << "                       stepIters, fallback, done, violFlag);\n"
+            << "                       stepIters, CSIM_AUX_ARGS);\n"
             << "    return (int)hipGetLastError();\n}\n";
     return src.str();
 }

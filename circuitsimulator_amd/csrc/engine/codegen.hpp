@@ -69,11 +69,22 @@ struct GeneratorOptions {
     int pipelineMos = 1;         // sixteen-lane kernel: 1 = the MOSFET pass and the staging reads of iteration i+1 run at
                                  // the end of iteration i, under its convergence bookkeeping; 0 = at the head of i+1
     int groupWavesPerEu = 0;     // sixteen-lane kernel: amdgpu_waves_per_eu(n, n) on the kernel (0 = leave it to the compiler)
-    bool set(const std::string& keyval);      // "barrier_every=3", "sweep=0,16,32", "stage_ahead=3", "pipeline_mos=0", "group_waves=2"
+    // Near-threshold guard of the FAST kernels (FMA contraction, reciprocal pivots).  A branch-deciding comparison
+    // whose two sides agree to within this relative band could fall the other way in the reference's arithmetic:
+    //  transient `err < tol` (src/tanalisis.cpp:369): the kernel goes on speculatively, keeps the state at the
+    //    start of that time step, and the engine has the bit-faithful generated kernel redo the step afterwards --
+    //    equal pass count: the speculation stands, else the instance is rolled back to that step;
+    //  DC `err < tol`, `err > prevErr * slow`, `err < prevErr * fast` (src/dcanalysis.cpp:150,285-296): the
+    //    instance is replayed by the bit-faithful DC kernel.
+    // Measured noise of err at the deciding pass, FMA against non-FMA build of the oracle on dbmixer.sp: transient
+    // median 9e-11, max 1.2e-9 (relative); DC up to 6e-7 (tol 1e-9 magnifies the solve's rounding).  0 = no guard.
+    double nearBand = 2e-8;
+    double nearBandDc = 1e-5;
+    bool set(const std::string& keyval);      // "barrier_every=3", "sweep=0,16,32", "stage_ahead=3", "pipeline_mos=0", "group_waves=2", "near_band=2e-8", "near_band_dc=1e-5"
 };
 
 // bumped whenever the emitted code or the launcher ABI of a generated library changes
-constexpr int kGeneratorRevision = 23;
+constexpr int kGeneratorRevision = 24;
 
 // identifies (topology, constants, schedule); names the generated library
 uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch);

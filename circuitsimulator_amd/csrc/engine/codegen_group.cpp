@@ -180,6 +180,8 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     const int nMos = static_cast<int>(gp.mosElem.size());
     const int mosRounds = (nMos + G - 1) / G;
     const int nStage = static_cast<int>(gp.stageRows.size());
+    // near-threshold guard (codegen.hpp GeneratorOptions::nearBand)
+    const bool guard = gopt.nearBand > 0.0;
 
     // LDS carve-up per instance (doubles)
     const int nT1 = ap.nTerms + 1;                              // + one dummy term (always 0) for padded table entries
@@ -266,7 +268,8 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
       << "                       double* __restrict__ wave, double* __restrict__ xio, long long* __restrict__ iters,\n"
       << "                       unsigned* __restrict__ status, int* __restrict__ stepIters,\n"
       << "                       unsigned char* __restrict__ fallback, int* __restrict__ done,\n"
-      << "                       int* __restrict__ violFlag)\n{\n"
+      << "                       int* __restrict__ violFlag, double* __restrict__ nearX, int* __restrict__ nearStep,\n"
+      << "                       int* __restrict__ nearIt, long long* __restrict__ nearItAfter)\n{\n"
       << "    __shared__ double lds[4 * " << instDoubles << "];\n"
       << "    const int lane = threadIdx.x, g = lane & 15, q = lane >> 4;\n"
       << "    const int b = blockIdx.x * 4 + q;\n"
@@ -358,6 +361,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
       << "    bool dead = !inb || (st & ST_TRAN_NONFINITE) != 0u;   // the reference would have thrown: stay stopped\n"
       << "    long long itTotal = 0;\n"
       << "    long long sdone = (inb && !dead) ? (long long)done[bb] : nSteps;\n"
+      << (guard ? "    int nearS = 0;          // step (of this launch) of the group's first near-threshold convergence decision; 0 = none\n" : "")
       << "    if (stepFirst == 0 && sdone == 0 && wave && inb)\n"
       << "        for (int pq = g; pq < nProbe; pq += 16) wave[((long long)pq) * SB + b] = XS[probeEq[pq]];\n";
     const bool piped = gopt.pipelineMos != 0 && mosRounds > 0 && nStage > 0;
@@ -656,13 +660,20 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
       << in << "// branch-free bookkeeping (everything here is uniform within a group of 16 lanes)\n"
       << in << "const bool good = active && !pv && (ss < 1.0e300);      // the solve stands: take the damped update\n"
       << in << "const bool conv = err < " << lit(K.tran_tol) << ";\n"
-      << in << "const bool slow = !conv && iter >= " << (slowIters - 1) << ";                 // slow step: plan.hpp slowStepIters\n"
-      << in << "viol = viol || (active && !good) || (good && slow);\n"
+      << in << "const bool slow = !conv && iter >= " << (slowIters - 1) << ";                 // slow step: plan.hpp slowStepIters\n";
+    if (guard)
+        // `err < tol` (tanalisis.cpp:369) decided within the rounding noise of this kernel's arithmetic: the group goes on
+        // speculatively, the step's start state is kept at the end of the step, and the engine verifies the pass count
+        // with the faithful kernel.  One checkpoint per launch: a second such step stops the group.
+        o << in << "const bool near = good && fabs(err - " << lit(K.tran_tol) << ") <= " << lit(gopt.nearBand * K.tran_tol) << ";\n"
+          << in << "const bool again = near && nearS != 0 && nearS != (int)s;\n"
+          << in << "nearS = (near && nearS == 0) ? (int)s : nearS;\n";
+    o << in << "viol = viol || (active && !good) || (good && slow)" << (guard ? " || again" : "") << ";\n"
       << in << "it += good ? 1 : 0;\n";
     for (int s = 0; s < S; ++s) o << in << "xo" << s << " = good ? xn" << s << " : xo" << s << ";\n";
     // the empty asm pins the loads of the next iteration's MOSFET inputs (and staging rows) to this side of the loop's
     // back edge (the compiler otherwise sinks them to the head of the next iteration, in front of what needs them)
-    o << in << "active = good && !conv && !slow;\n"
+    o << in << "active = good && !conv && !slow" << (guard ? " && !again" : "") << ";\n"
       << in << "__builtin_amdgcn_sched_barrier(0);\n";
     if (piped) {
         for (int r0 = 0; r0 < nStage; r0 += 12) {
@@ -676,8 +687,15 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     }
     o
       << "        }\n"      // NR loop
-      << "        if (live && !viol) {\n"
-      << "            itTotal += it;\n"
+      << "        if (live && !viol) {\n";
+    if (guard) {
+        o << "            if (nearS == (int)s) {     // keep the state at the start of this step for the verification\n";
+        for (int s = 0; s < S; ++s)
+            o << "                if (" << s * G << " + g < " << N << ") nearX[(long long)(" << s * G << " + g) * SB + b] = XP[" << s * G << " + g];\n";
+        o << "                if (g == 0) { nearStep[b] = (int)s; nearIt[b] = it; nearItAfter[b] = itTotal; }\n"
+          << "            }\n";
+    }
+    o << "            itTotal += it;\n"
       << "            if (stepIters && g == 0) stepIters[(s - 1) * SB + b] = it;\n"
       << "            if (wave && ophase == 0) {\n"
       << "                const long long row = orow;\n"
@@ -691,10 +709,12 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     for (int s = 0; s < S; ++s)
         o << "        if (" << s * G << " + g < " << N << ") xio[(long long)(" << s * G << " + g) * SB + b] = viol ? XP[" << s * G << " + g] : xo" << s << ";\n";
     o << "        if (g == 0) {\n"
-      << "            if (viol) { fallback[b] = 1; *violFlag = 1; }\n"
+      << "            if (viol) fallback[b] = 1;\n"
       << "            iters[b] += itTotal;\n"
       << "            status[b] |= st;\n"
       << "            done[b] = (int)sdone;\n"
+      << "            if (sdone < nSteps) violFlag[0] = 1;      // unfinished: the engine goes on with this instance\n"
+      << (guard ? "            if (nearS != 0 && sdone >= nearS) { nearItAfter[b] = itTotal - nearItAfter[b]; violFlag[1] = 1; }   // to be verified\n" : "")
       << "        }\n"
       << "    }\n"
       << "}\n\n";

@@ -145,6 +145,7 @@ void adoptScheduleTable(csim_engine* eng, void* lib)
     eng->schedGroupLanes = lanesFn ? lanesFn() : 0;
     LanesFn faithFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_has_faithful"));
     eng->schedHasFaithful = faithFn && faithFn() != 0;
+    if (eng->kernelChoice == 3 && !eng->schedHasFaithful) eng->kernelChoice = 0;    // a reload dropped the faithful kernel
     LanesFn workFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_work_doubles"));
     eng->schedWorkDoubles = workFn ? workFn() : 0;
     // DC operating-point kernel, present when the library was generated with "dc" schedules
@@ -185,6 +186,9 @@ EngineConfig configFromEnvironment()
     c.jitTimeoutSec = std::max(1, envInt("CSIM_JIT_TIMEOUT", c.jitTimeoutSec));
     c.jitDcAlts = std::max(0, std::min(8, envInt("CSIM_JIT_DC_ALTS", c.jitDcAlts)));
     c.jitDcForce = std::getenv("CSIM_JIT_DC_FORCE") != nullptr;
+    c.hybridSync = envInt("CSIM_HYBRID_SYNC", 1) != 0;
+    c.dcFast = envInt("CSIM_DC_FAST", 0) != 0;
+    if (c.lanesPerInstance != 0 && c.lanesPerInstance != 1 && c.lanesPerInstance != 16) c.lanesPerInstance = 0;
     return c;
 }
 
@@ -275,7 +279,11 @@ void csim_engine_destroy(csim_engine* eng)
     (void)hipSetDevice(eng->device);
     for (void* p : eng->owned) (void)hipFree(p);
     if (eng->dFallback) (void)hipFree(eng->dFallback);
+    if (eng->dFallback2) (void)hipFree(eng->dFallback2);
     if (eng->dDone) (void)hipFree(eng->dDone);
+    for (void* p : {(void*)eng->dNearX, (void*)eng->dVerX, (void*)eng->dNearStep, (void*)eng->dNearIt, (void*)eng->dVerDone,
+                    (void*)eng->dNearItAfter, (void*)eng->dVerIters, (void*)eng->dVerStatus, (void*)eng->dVerFallback})
+        if (p) (void)hipFree(p);
     if (eng->dSchedWork) (void)hipFree(eng->dSchedWork);
     if (eng->dViolFlag) (void)hipFree(eng->dViolFlag);
     if (eng->hViolFlag) (void)hipHostFree(eng->hViolFlag);
@@ -323,6 +331,10 @@ int csim_engine_set_option(csim_engine* eng, const char* key, const char* value)
     else if (k == "sched_variant") c.schedVariant = iv;
     else if (k == "lanes_per_instance") {
         if (iv != 0 && iv != 1 && iv != 16) { setError("lanes_per_instance must be 0 (auto), 1 or 16"); return CSIM_ERR_ARG; }
+        if (iv == 16 && eng->schedLaunch && eng->schedGroupLanes != 16) {
+            setError("lanes_per_instance=16: the loaded kernel library has no sixteen-lanes-per-instance kernel");
+            return CSIM_ERR_UNSUPPORTED;
+        }
         c.lanesPerInstance = iv;
     }
     else if (k == "auto_jit") c.autoJit = iv != 0;
@@ -331,8 +343,21 @@ int csim_engine_set_option(csim_engine* eng, const char* key, const char* value)
     else if (k == "jit_timeout") c.jitTimeoutSec = std::max(1, iv);
     else if (k == "jit_dc_alts") c.jitDcAlts = std::max(0, std::min(8, iv));
     else if (k == "jit_dc_force") c.jitDcForce = iv != 0;
+    else if (k == "jit_gen_opts") c.jitGenOpts = v;
+    else if (k == "near_test_rollback") c.nearTestRollback = iv != 0;
+    else if (k == "hybrid_sync") c.hybridSync = iv != 0;
+    else if (k == "dc_fast") c.dcFast = iv != 0;
     else { setError("csim_engine_set_option: unknown option '" + k + "'"); return CSIM_ERR_ARG; }
     return CSIM_OK;
+}
+
+int64_t csim_engine_stat(const csim_engine* eng, const char* key)
+{
+    if (!eng || !key) return -1;
+    const std::string k(key);
+    if (k == "near_verified") return eng->nearVerified;
+    if (k == "near_rolled_back") return eng->nearRolledBack;
+    return -1;
 }
 
 int csim_mc_params_dev(csim_engine* eng, uint64_t seed, double sigma, int64_t b_first,
@@ -346,13 +371,14 @@ int csim_mc_params_dev(csim_engine* eng, uint64_t seed, double sigma, int64_t b_
     return CSIM_OK;
 }
 
-// Did any instance leave the scheduled kernel unfinished?  One int comes back from the device; the
-// call waits for the stream here (the follow-up launches depend on the answer).
-static int readViolFlag(csim_engine* eng, hipStream_t hs, bool* any)
+// The device's flag words of the hand-over protocol -> host.  Synchronous mode (cfg.hybridSync) only: the call
+// waits for the stream here, because which launches follow depends on the answer.
+static int readFlags(csim_engine* eng, hipStream_t hs, bool* unfinished, bool* toVerify)
 {
-    HIPCHK(hipMemcpyAsync(eng->hViolFlag, eng->dViolFlag, sizeof(int32_t), hipMemcpyDeviceToHost, hs));
+    HIPCHK(hipMemcpyAsync(eng->hViolFlag, eng->dViolFlag, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, hs));
     HIPCHK(hipStreamSynchronize(hs));
-    *any = *eng->hViolFlag != 0;
+    *unfinished = eng->hViolFlag[0] != 0;
+    if (toVerify) *toVerify = eng->hViolFlag[1] != 0;
     return CSIM_OK;
 }
 
@@ -361,8 +387,10 @@ static int readViolFlag(csim_engine* eng, hipStream_t hs, bool* any)
 static int schedVariantFor(const csim_engine* eng, int32_t B)
 {
     if (eng->cfg.schedVariant != 0) return eng->cfg.schedVariant;
-    if (eng->cfg.lanesPerInstance == 16) return 16;
-    if (eng->cfg.lanesPerInstance == 1) return 0;
+    // (a library without the sixteen-lane kernel -- a linear circuit's, or one loaded after the option was set --
+    // runs its lane-per-instance kernel whatever the option says)
+    if (eng->cfg.lanesPerInstance == 16 && eng->schedGroupLanes == 16) return 16;
+    if (eng->cfg.lanesPerInstance == 1 || eng->cfg.lanesPerInstance == 16) return 0;
     // auto: sixteen lanes per instance while the batch is too small to give every SIMD a wave of 64
     // instances.  Measured on dbmixer (gpurun_out/sw9): 16 lanes 2.4-2.5e9 NR-iter*inst/s from B = 4096 up (one
     // wave per SIMD, further instances run as further rounds), one lane 8.6e8 at B = 4096 growing linearly --
@@ -377,22 +405,49 @@ extern "C" int csim_engine_lanes_for_batch(const csim_engine* eng, int32_t B)
     return schedVariantFor(eng, B) == 16 ? 16 : 1;
 }
 
-// per-instance fallback mask and progress counters of the scheduled kernels
+// per-instance hand-over masks, progress counters and flag words of the generated kernels
 static int ensureFallbackBuffers(csim_engine* eng, int32_t B)
 {
     if (!eng->dViolFlag) {
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dViolFlag), sizeof(int32_t)));
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&eng->hViolFlag), sizeof(int32_t), hipHostMallocDefault));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dViolFlag), 8 * sizeof(int32_t)));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&eng->hViolFlag), 4 * sizeof(int32_t), hipHostMallocDefault));
     }
     if (eng->fallbackCap >= B) return CSIM_OK;
     if (eng->dFallback) HIPCHK(hipFree(eng->dFallback));
+    if (eng->dFallback2) HIPCHK(hipFree(eng->dFallback2));
     if (eng->dDone) HIPCHK(hipFree(eng->dDone));
-    eng->dFallback = nullptr;
+    eng->dFallback = eng->dFallback2 = nullptr;
     eng->dDone = nullptr;
     eng->fallbackCap = 0;
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dFallback), (size_t)B));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dFallback2), (size_t)B));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dDone), sizeof(int32_t) * (size_t)B));
     eng->fallbackCap = B;
+    return CSIM_OK;
+}
+
+// buffers of the near-threshold verification (kernels_verify.hip)
+static int ensureNearBuffers(csim_engine* eng, int32_t B)
+{
+    if (eng->nearCap >= B) return CSIM_OK;
+    void** all[] = {reinterpret_cast<void**>(&eng->dNearX), reinterpret_cast<void**>(&eng->dVerX),
+                    reinterpret_cast<void**>(&eng->dNearStep), reinterpret_cast<void**>(&eng->dNearIt),
+                    reinterpret_cast<void**>(&eng->dVerDone), reinterpret_cast<void**>(&eng->dNearItAfter),
+                    reinterpret_cast<void**>(&eng->dVerIters), reinterpret_cast<void**>(&eng->dVerStatus),
+                    reinterpret_cast<void**>(&eng->dVerFallback)};
+    for (void** p : all) { if (*p) HIPCHK(hipFree(*p)); *p = nullptr; }
+    eng->nearCap = 0;
+    const size_t N = (size_t)eng->plan.N, n = (size_t)B;
+    HIPCHK(hipMalloc(all[0], sizeof(double) * N * n));
+    HIPCHK(hipMalloc(all[1], sizeof(double) * N * n));
+    HIPCHK(hipMalloc(all[2], sizeof(int32_t) * n));
+    HIPCHK(hipMalloc(all[3], sizeof(int32_t) * n));
+    HIPCHK(hipMalloc(all[4], sizeof(int32_t) * n));
+    HIPCHK(hipMalloc(all[5], sizeof(long long) * n));
+    HIPCHK(hipMalloc(all[6], sizeof(long long) * n));
+    HIPCHK(hipMalloc(all[7], sizeof(uint32_t) * n));
+    HIPCHK(hipMalloc(all[8], n));
+    eng->nearCap = B;
     return CSIM_OK;
 }
 
@@ -412,21 +467,40 @@ int csim_dc_batch_dev(csim_engine* eng, const double* d_params, int32_t B, doubl
         return CSIM_OK;
     }
     hipStream_t hs = static_cast<hipStream_t>(stream);
-    // (kernel family 3, "faithful": there is no faithful generated DC kernel, the general one is bit-faithful)
-    if (eng->schedDcLaunch && eng->kernelChoice != 1 && eng->kernelChoice != 3) {
-        // lane-per-instance kernel on the recorded DC pivot sequences; an instance that fails a pivot
-        // check (or meets a non-finite solve) is replayed from x = 0 by the general kernel
+    if (eng->schedDcLaunch && eng->kernelChoice != 1) {
+        // Generated lane-per-instance kernels on the recorded DC pivot sequences, as a chain in which every
+        // kernel replays, from x = 0, exactly the instances the one before could not finish (mask):
+        //   [fast kernel (option dc_fast): contraction, reciprocal pivots; leaves an instance on a failed pivot
+        //    check, a non-finite solve, a final ramp step at the NR cap, or a controller decision within its
+        //    rounding noise (src/dcanalysis.cpp:150,285-296) ->]
+        //   faithful kernel: the reference's operations, bit for bit the general kernel's operating points;
+        //    leaves an instance on a failed pivot check or a non-finite solve ->
+        //   general kernel (run-time pivoting).
         const int rc = ensureFallbackBuffers(eng, B);
         if (rc) return rc;
-        HIPCHK(hipMemsetAsync(eng->dFallback, 0, (size_t)B, hs));
-        HIPCHK(hipMemsetAsync(eng->dViolFlag, 0, sizeof(int32_t), hs));
-        if (eng->schedDcLaunch(d_params, B, d_x, d_iters, d_status, eng->dFallback, eng->dViolFlag, stream) != 0) {
-            setError("scheduled DC kernel launch failed");
-            return CSIM_ERR_HIP;
-        }
+        const bool sync = eng->cfg.hybridSync;
+        const bool fast = eng->cfg.dcFast && eng->kernelChoice != 3;
+        auto stage = [&](int variant, unsigned char* leaves, const unsigned char* only, bool* any) -> int {
+            HIPCHK(hipMemsetAsync(leaves, 0, (size_t)B, hs));
+            HIPCHK(hipMemsetAsync(eng->dViolFlag, 0, 4 * sizeof(int32_t), hs));
+            if (eng->schedDcLaunch(d_params, B, d_x, d_iters, d_status, leaves, eng->dViolFlag, only, stream, variant) != 0) {
+                setError("scheduled DC kernel launch failed");
+                return CSIM_ERR_HIP;
+            }
+            *any = true;
+            return sync ? readFlags(eng, hs, any, nullptr) : CSIM_OK;
+        };
         bool any = false;
-        if (const int frc = readViolFlag(eng, hs, &any)) return frc;
-        if (any) HIPCHK(csim::launchDcGeneral(eng->gpDc, d_params, B, d_x, d_iters, d_status, hs, eng->dFallback));
+        const unsigned char* left = nullptr;
+        if (fast) {
+            if (const int frc = stage(2, eng->dFallback, nullptr, &any)) return frc;
+            if (!any) return CSIM_OK;
+            left = eng->dFallback;
+        }
+        unsigned char* mine = fast ? eng->dFallback2 : eng->dFallback;
+        if (const int frc = stage(0, mine, left, &any)) return frc;
+        if (!any) return CSIM_OK;
+        HIPCHK(csim::launchDcGeneral(eng->gpDc, d_params, B, d_x, d_iters, d_status, hs, mine));
         return CSIM_OK;
     }
     HIPCHK(csim::launchDcGeneral(eng->gpDc, d_params, B, d_x, d_iters, d_status, hs));
@@ -474,49 +548,106 @@ int csim_tran_batch_dev(csim_engine* eng, const double* d_params, int32_t B, dou
     // general kernel writes that row; the hybrid sequence below would return before it
     if (!(eng->schedLaunch && eng->kernelChoice != 1) || n_steps == 0) return general(nullptr, 0);
 
-    // Fast path with hybrid stepping.  The generated kernel advances every instance until the launch
-    // is complete or one of its checks fails (no recorded schedule fits that factorisation, or the
-    // Newton iteration of a step ends at its cap); it keeps the state at the start of the failing
-    // step and records per-instance progress in dDone.  One int tells the host whether any instance
-    // is unfinished: if none is (the usual case) the call ends after ONE launch.  Otherwise the
-    // general kernel advances the unfinished instances with run-time pivoting until a whole step
-    // ran on recorded sequences again and hands them back, for at most cfg.hybridRounds rounds.
+    // Fast path with a hand-over ladder.  The generated kernel advances every instance until the launch is
+    // complete or one of its checks fails (no recorded schedule fits that factorisation, or the Newton
+    // iteration of a step is slow, plan.hpp slowStepIters); it keeps the state at the start of the failing
+    // step and records per-instance progress in dDone.  Device flag [0] says whether any instance is
+    // unfinished: if none is -- the usual case -- the call ends after ONE launch.
+    //
+    // Near-threshold decisions (codegen.hpp GeneratorOptions::nearBand).  A fast kernel that takes an
+    // `err < tol` decision (src/tanalisis.cpp:369) within its own rounding noise goes on speculatively and
+    // leaves the state at the start of that step; flag [1] then asks for a verification: the FAITHFUL
+    // generated kernel (the reference's arithmetic on the recorded sequences) redoes exactly that step for
+    // exactly those instances (kernels_verify.hip), and an instance whose pass count differs is rolled back
+    // to that step and handed to the ladder with reason 2: the faithful kernel runs that one step, the fast
+    // kernel has the instance back.
+    //
+    // Ladder for unfinished instances: (1) the faithful kernel -- slow / non-convergent steps are redone there
+    // bit-faithfully at lane-per-instance speed; it leaves an instance only when no recorded sequence fits;
+    // (2) the fast kernel again (instances handed back after their one faithful step); (3) the general
+    // kernel with run-time pivoting, which hands an instance back once a whole step ran on recorded
+    // sequences again; at most cfg.hybridRounds rounds, then the general kernel runs what is left.
+    //
+    // cfg.hybridSync (default): the host reads the flags after each stage and returns as soon as nothing is
+    // left.  With hybrid_sync = 0 the call never waits: the same sequence of launches is enqueued
+    // unconditionally (every kernel returns at once when it finds nothing to do; 10 launches per hybrid round,
+    // a few microseconds each) -- bit for bit the synchronous results, for callers that overlap streams or
+    // capture graphs.
     {
         const int rc = ensureFallbackBuffers(eng, B);
         if (rc) return rc;
     }
+    const bool linearLib = eng->schedWorkDoubles > 0;
+    const bool canVerify = !linearLib && eng->schedHasFaithful;
+    if (!linearLib) {
+        const int rc = ensureNearBuffers(eng, B);
+        if (rc) return rc;
+    }
     HIPCHK(hipMemsetAsync(eng->dFallback, 0, (size_t)B, hs));
     HIPCHK(hipMemsetAsync(eng->dDone, 0, sizeof(int32_t) * (size_t)B, hs));
-    if (eng->schedWorkDoubles > 0 && eng->schedWorkCap < B) {      // factor store of the linear-circuit kernel
+    HIPCHK(hipMemsetAsync(eng->dViolFlag, 0, 8 * sizeof(int32_t), hs));
+    if (!linearLib) HIPCHK(hipMemsetAsync(eng->dNearStep, 0, sizeof(int32_t) * (size_t)B, hs));
+    if (linearLib && eng->schedWorkCap < B) {      // factor store of the linear-circuit kernel
         if (eng->dSchedWork) HIPCHK(hipFree(eng->dSchedWork));
         eng->dSchedWork = nullptr;
         eng->schedWorkCap = 0;
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dSchedWork), sizeof(double) * (size_t)eng->schedWorkDoubles * ((size_t)B + 64)));   // whole workgroups
         eng->schedWorkCap = B;
     }
-    auto scheduled = [&](int variant, bool* anyUnfinished) -> int {
-        HIPCHK(hipMemsetAsync(eng->dViolFlag, 0, sizeof(int32_t), hs));
-        const int lrc = eng->schedLaunch(d_params, B, tstep, step_first, n_steps, dProbe, np, os, d_wave, d_x,
-                                         reinterpret_cast<long long*>(d_iters), d_status, d_step_iters,
-                                         eng->dFallback, eng->dDone, eng->dViolFlag, eng->dSchedWork, stream, variant);
+    const bool sync = eng->cfg.hybridSync;
+    csim_sched_aux aux{eng->dFallback, eng->dDone, eng->dViolFlag, eng->dSchedWork,
+                       eng->dNearX, eng->dNearStep, eng->dNearIt, eng->dNearItAfter};
+    auto launchSched = [&](int variant, const csim_sched_aux& a, double* x, long long* it, uint32_t* st, bool outputs) -> int {
+        const int lrc = eng->schedLaunch(d_params, B, tstep, step_first, n_steps, outputs ? dProbe : nullptr, outputs ? np : 0,
+                                         outputs ? os : 1, outputs ? d_wave : nullptr, x, it, st,
+                                         outputs ? d_step_iters : nullptr, &a, stream, variant);
         if (lrc != 0) { setError(std::string("scheduled kernel launch: ") + hipGetErrorString((hipError_t)lrc)); return CSIM_ERR_HIP; }
-        return readViolFlag(eng, hs, anyUnfinished);
+        return CSIM_OK;
     };
-    // Kernel ladder for an instance that leaves the fast kernel: (1) the FAITHFUL generated kernel -- same
-    // recorded pivot sequences, the reference's arithmetic (true divisions, no contraction, no slow-step
-    // rule), so slow / non-convergent steps are redone there bit-faithfully at lane-per-instance speed; it
-    // stops an instance only when no recorded sequence fits; (2) the general kernel with run-time pivoting,
-    // which hands the instance back once a whole step ran on recorded sequences again.
+    // the faithful kernel redoes the flagged steps on scratch copies; the pass counts decide (kernels_verify.hip)
+    auto verify = [&]() -> int {
+        HIPCHK(csim::launchNearPrep(B, eng->plan.N, n_steps, eng->dNearStep, eng->dNearX, eng->dVerX, eng->dVerDone,
+                                    eng->dVerIters, eng->dVerStatus, eng->dVerFallback, hs));
+        const csim_sched_aux va{eng->dVerFallback, eng->dVerDone, eng->dViolFlag + 4, nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (const int rc = launchSched(3, va, eng->dVerX, eng->dVerIters, eng->dVerStatus, false)) return rc;
+        HIPCHK(csim::launchNearResolve(B, eng->plan.N, eng->dNearStep, eng->dNearIt, eng->dNearItAfter, eng->dNearX,
+                                       eng->dVerDone, eng->dVerIters, d_x, eng->dDone,
+                                       reinterpret_cast<long long*>(d_iters), eng->dFallback, eng->dViolFlag,
+                                       eng->cfg.nearTestRollback, hs));
+        return CSIM_OK;
+    };
+    // one launch of a generated kernel on the caller's buffers (+ its verification); *unfinished: may any
+    // instance be unfinished afterwards (asynchronous mode: always "maybe")
+    auto scheduled = [&](int variant, bool* unfinished) -> int {
+        HIPCHK(hipMemsetAsync(eng->dViolFlag, 0, 2 * sizeof(int32_t), hs));
+        if (const int rc = launchSched(variant, aux, d_x, reinterpret_cast<long long*>(d_iters), d_status, true)) return rc;
+        const bool speculates = canVerify && variant != 3;
+        *unfinished = true;
+        if (!sync) return speculates ? verify() : CSIM_OK;
+        bool toVerify = false;
+        if (const int rc = readFlags(eng, hs, unfinished, &toVerify)) return rc;
+        if (speculates && toVerify) {
+            if (const int rc = verify()) return rc;
+            if (const int rc = readFlags(eng, hs, unfinished, nullptr)) return rc;
+            eng->nearVerified += eng->hViolFlag[2];
+            eng->nearRolledBack += eng->hViolFlag[3];
+            HIPCHK(hipMemsetAsync(eng->dViolFlag + 2, 0, 2 * sizeof(int32_t), hs));
+        }
+        return CSIM_OK;
+    };
     const bool faithfulOnly = eng->kernelChoice == 3 && eng->schedHasFaithful;
     const int fast = faithfulOnly ? 3 : schedVariantFor(eng, B);
     bool unfinished = false;
     int rc = scheduled(fast, &unfinished);
     if (rc || !unfinished) return rc;
-    for (int r = 0; r <= eng->cfg.hybridRounds; ++r) {
+    const int rounds = eng->cfg.hybridRounds;
+    for (int r = 0; r <= rounds; ++r) {
         if (eng->schedHasFaithful && !faithfulOnly) {
             if ((rc = scheduled(3, &unfinished)) || !unfinished) return rc;
+            // instances that had one faithful step go on here; one that no recorded sequence fits stops again at once
+            if ((rc = scheduled(fast, &unfinished)) || !unfinished) return rc;
         }
-        if (r == eng->cfg.hybridRounds) break;
+        if (r == rounds) break;
         if ((rc = general(eng->dDone, eng->cfg.hybridSteps, true))) return rc;
         if ((rc = scheduled(fast, &unfinished)) || !unfinished) return rc;
     }
@@ -959,7 +1090,17 @@ static int buildAndLoadScheduled(csim_engine* eng, const csim::ScheduleSet& sch)
     const csim_ir* ir = eng->cir.view();
     const int N = ir->n_unknowns;
     const unsigned long long topo = csim::scheduleHash(*ir, csim::PivotSchedule::identity(N));
-    const unsigned long long full = csim::scheduleHash(*ir, sch);
+    // generator options of this engine's JIT (option jit_gen_opts: "key=value,key=value"; part of the library's hash)
+    csim::GeneratorOptions gopt;
+    for (std::size_t i = 0; i < eng->cfg.jitGenOpts.size();) {
+        std::size_t e = eng->cfg.jitGenOpts.find(',', i);
+        if (e == std::string::npos) e = eng->cfg.jitGenOpts.size();
+        // "sweep" takes a comma list itself and is a tuning aid of csim_codegen only
+        const std::string kv = eng->cfg.jitGenOpts.substr(i, e - i);
+        if (!kv.empty() && !gopt.set(kv)) { setError("jit_gen_opts: unknown generator option '" + kv + "'"); return CSIM_ERR_ARG; }
+        i = e + 1;
+    }
+    const unsigned long long full = csim::scheduleHash(*ir, sch, gopt);
     const std::string dir = eng->cfg.jitDir;
     {
         const std::string why = csim::jitPrepareDir(dir);
@@ -984,7 +1125,7 @@ static int buildAndLoadScheduled(csim_engine* eng, const csim::ScheduleSet& sch)
     };
     void* handle = openChecked(lib);
     if (!handle) {
-        const std::string src = csim::generateTranKernelSource(*ir, eng->plan, sch, "jit", nullptr);
+        const std::string src = csim::generateTranKernelSource(*ir, eng->plan, sch, "jit", nullptr, gopt);
         if (src.empty()) { setError("circuit too large for a scheduled kernel (iterate does not fit LDS)"); return CSIM_ERR_UNSUPPORTED; }
         // several ranks may specialise the same circuit at once: private temporaries, atomic rename
         const std::string tag = "." + std::to_string((long long)getpid());

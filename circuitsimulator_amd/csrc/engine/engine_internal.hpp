@@ -22,6 +22,21 @@ struct EngineConfig {
     int jitTimeoutSec = 600;     // jit_timeout    / CSIM_JIT_TIMEOUT: wall-clock limit of one compile
     int jitDcAlts = 4;           // jit_dc_alts    / CSIM_JIT_DC_ALTS: most DC sequences a JIT kernel may carry
     bool jitDcForce = false;     // jit_dc_force   / CSIM_JIT_DC_FORCE: keep a partial DC cover (tests)
+    bool hybridSync = true;      // hybrid_sync    / CSIM_HYBRID_SYNC: 1 = the host reads the device's "unfinished" flags between
+                                 // the launches of the hand-over ladder and stops as soon as nothing is left (the usual
+                                 // case: ONE launch per call); 0 = the whole ladder is enqueued unconditionally, every
+                                 // kernel returns at once when it has nothing to do, and the call never waits on the stream
+    std::string jitGenOpts;      // jit_gen_opts: generator options of this engine's JIT, "key=value,key=value" (codegen.hpp)
+    bool nearTestRollback = false;   // near_test_rollback: test aid -- every verified near-threshold decision counts as a
+                                 // mismatch, so the roll-back path runs (results must not change)
+    bool dcFast = false;         // dc_fast        / CSIM_DC_FAST: 1 = DC operating points start on the fast generated kernel
+                                 // (contraction, reciprocal pivots, guarded decisions) instead of the faithful one
+};
+
+// auxiliaries of a generated library's csim_sched_launch (same struct in the generated source, codegen.cpp)
+struct csim_sched_aux {
+    unsigned char* fallback; int* done; int* flags; double* work;
+    double* nearX; int* nearStep; int* nearIt; long long* nearItAfter;
 };
 
 struct csim_engine {
@@ -44,9 +59,9 @@ struct csim_engine {
 
     // circuit-specialised transient kernel (side library libcsim_sched_<topology>.so)
     typedef int (*SchedLaunchFn)(const double*, int, double, long long, long long, const int*, int, int,
-                                 double*, double*, long long*, unsigned*, int*, unsigned char*, int*, int*, double*, void*, int);
+                                 double*, double*, long long*, unsigned*, int*, const csim_sched_aux*, void*, int);
     // DC operating point of the same library (nullptr: the library carries no DC schedule)
-    typedef int (*SchedDcLaunchFn)(const double*, int, double*, int*, unsigned*, unsigned char*, int*, void*);
+    typedef int (*SchedDcLaunchFn)(const double*, int, double*, int*, unsigned*, unsigned char*, int*, const unsigned char*, void*, int);
     void* schedLib = nullptr;
     SchedLaunchFn schedLaunch = nullptr;
     SchedDcLaunchFn schedDcLaunch = nullptr;
@@ -58,11 +73,22 @@ struct csim_engine {
     int schedGroupLanes = 0;               // 16 when the library also carries the sixteen-lanes-per-instance kernel
     int32_t* dKnownAlts = nullptr;         // [nKnownAlts][N] pivot sequences the loaded kernel carries
     int nKnownAlts = 0;
-    unsigned char* dFallback = nullptr;    // per-instance "a schedule check failed in this launch" mask
+    unsigned char* dFallback = nullptr;    // per-instance reason an instance left a generated kernel (codegen.cpp csim_sched_aux)
+    unsigned char* dFallback2 = nullptr;   // second mask of the DC chain fast -> faithful -> general
     int32_t* dDone = nullptr;              // per-instance steps of the current launch already completed
     int fallbackCap = 0;
-    int32_t* dViolFlag = nullptr;          // one int: "some instance left the scheduled kernel unfinished"
-    int32_t* hViolFlag = nullptr;          // its pinned host mirror
+    int32_t* dViolFlag = nullptr;          // four ints: [0] some instance unfinished, [1] near-threshold decisions to verify,
+                                           // [2],[3] the same pair for the verification launch (scratch)
+    int32_t* hViolFlag = nullptr;          // pinned host mirror of [0..1]
+    // near-threshold verification (codegen.hpp GeneratorOptions::nearBand; kernels_verify.hip)
+    double* dNearX = nullptr;              // [N][B] state at the start of an instance's first near-threshold step
+    double* dVerX = nullptr;               // [N][B] the faithful kernel redoes that step here
+    int32_t *dNearStep = nullptr, *dNearIt = nullptr, *dVerDone = nullptr;
+    long long *dNearItAfter = nullptr, *dVerIters = nullptr;
+    uint32_t* dVerStatus = nullptr;
+    unsigned char* dVerFallback = nullptr;
+    int nearCap = 0;
+    long long nearVerified = 0, nearRolledBack = 0;   // statistics (host-visible in synchronous mode only)
 
     // large circuits (N > 63): dense scratch matrices in global memory, one per instance
     bool big = false;

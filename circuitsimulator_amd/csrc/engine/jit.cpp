@@ -67,8 +67,20 @@ std::string jitRun(const std::vector<std::string>& argv, const std::string& logP
     posix_spawnattr_init(&at);
     posix_spawnattr_setflags(&at, POSIX_SPAWN_SETPGROUP);      // own process group: the timeout kills the compiler's children too
     posix_spawnattr_setpgroup(&at, 0);
+    // The compiler must not inherit a profiler's or tool's preload: under rocprofv3 the preloaded library has
+    // initialised the GPU in this process, and every exec of the hipcc -> clang -> lld chain with that
+    // environment would be an exec from a GPU-initialised process image (forbidden on some pools).
+    std::vector<char*> envp;
+    for (char** e = environ; e && *e; ++e) {
+        static const char* const drop[] = {"LD_PRELOAD=", "ROCP_TOOL_LIBRARIES=", "ROCPROFILER_", "ROCPROF_", "ROCP_",
+                                           "HSA_TOOLS_LIB=", "HSA_TOOLS_REPORT_LOAD_FAILURE=", "ROCTRACER_", "OMPT_TOOL_LIBRARIES="};
+        bool keep = true;
+        for (const char* d : drop) keep = keep && std::strncmp(*e, d, std::strlen(d)) != 0;
+        if (keep) envp.push_back(*e);
+    }
+    envp.push_back(nullptr);
     pid_t pid = 0;
-    const int rc = posix_spawn(&pid, av[0], &fa, &at, av.data(), environ);
+    const int rc = posix_spawn(&pid, av[0], &fa, &at, av.data(), envp.data());
     posix_spawn_file_actions_destroy(&fa);
     posix_spawnattr_destroy(&at);
     if (rc != 0) return std::string("cannot start ") + argv[0] + ": " + std::strerror(rc);

@@ -62,6 +62,15 @@ hipError_t launchGsSolve(int n, int B, const double* dAt /*[n*n][B]*/, const dou
 hipError_t launchDcGs(const GenPlan& pl, const int32_t* dRowPtr, const int32_t* dRowCol, const double* dParams, int B,
                       double* dX, int32_t* dIters, uint32_t* dStatus, hipStream_t stream);
 
+// near-threshold verification of the fast generated kernels (kernels_verify.hip)
+hipError_t launchNearPrep(int B, int N, long long nSteps, const int32_t* dNearStep, const double* dNearX, double* dVerX,
+                          int32_t* dVerDone, long long* dVerIters, uint32_t* dVerStatus, unsigned char* dVerFallback,
+                          hipStream_t stream);
+hipError_t launchNearResolve(int B, int N, int32_t* dNearStep, const int32_t* dNearIt, const long long* dNearItAfter,
+                             const double* dNearX, const int32_t* dVerDone, const long long* dVerIters, double* dX,
+                             int32_t* dDone, long long* dIters, unsigned char* dFallback, int32_t* dFlags,
+                             bool forceMismatch, hipStream_t stream);
+
 // Monte-Carlo parameter table (mc.hip)
 hipError_t launchMcParams(int P, int B, long long bFirst, uint64_t seed, double sigma,
                           const int32_t* dKind, const double* dNominal, const double* dMu,

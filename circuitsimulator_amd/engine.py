@@ -163,6 +163,10 @@ class Engine:
         """csim_engine_set_option: hybrid_rounds, hybrid_steps, lanes_per_instance, jit_dir, ... (include/csim.h)"""
         capi.check(capi.lib().csim_engine_set_option(self._h, str(key).encode(), str(value).encode()))
 
+    def stat(self, key):
+        """csim_engine_stat: "near_verified", "near_rolled_back" (include/csim.h)"""
+        return int(capi.lib().csim_engine_stat(self._h, str(key).encode()))
+
     # -- device-pointer forms (torch tensors on cuda:<device>, slot-major) ----
     def _dev(self):
         return "cuda:%d" % self.device

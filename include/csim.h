@@ -27,9 +27,20 @@
  * i*B + b, b = instance.  That is the coalesced layout for the
  * lane-per-instance kernels and costs the wave-per-instance kernels one
  * strided read per launch.  The *_dev entry points take DEVICE pointers in
- * that layout and enqueue on the given HIP stream without synchronising; the
- * host-pointer entry points take the instance-major tables proposed in
- * SURVEY.md 8(b) ([B][P], [B][N]) and do the copies and transposes.
+ * that layout and enqueue on the given HIP stream; the host-pointer entry
+ * points take the instance-major tables proposed in SURVEY.md 8(b) ([B][P],
+ * [B][N]) and do the copies and transposes.
+ *
+ * Streams.  With the default option hybrid_sync = 1 a *_dev call that runs
+ * generated ("scheduled") kernels WAITS on its stream once per stage of the
+ * hand-over ladder to read two flag words -- usually once per call -- and
+ * returns as soon as no instance is left unfinished.  With hybrid_sync = 0
+ * such a call only enqueues (a fixed sequence of launches, each returning at
+ * once when it finds nothing to do) and never waits: use that to overlap
+ * streams or to capture a HIP graph.  Calls on engines without a generated
+ * kernel never wait.  An engine owns ONE set of hand-over buffers: calls on
+ * the same engine must be ordered with respect to each other (same stream, or
+ * event-ordered); use one engine per concurrent stream.
  */
 #ifndef CSIM_H
 #define CSIM_H
@@ -136,8 +147,23 @@ int  csim_engine_set_kernel(csim_engine* eng, int32_t which);
  *                                           user are ever loaded from it
  *   hipcc (CSIM_HIPCC, /opt/rocm/bin/hipcc), jit_timeout (CSIM_JIT_TIMEOUT, 600 s)
  *   jit_dc_alts (CSIM_JIT_DC_ALTS, 4), jit_dc_force (CSIM_JIT_DC_FORCE, off)  DC schedules kept by the JIT
+ *   jit_gen_opts                            generator options of this engine's JIT, "key=value,key=value"
+ *                                           (near_band, near_band_dc, stage_ahead, ...: engine/codegen.hpp);
+ *                                           they are part of the hash a cached library is checked against
+ *   near_test_rollback (0)                  test aid: every verified near-threshold decision is treated as a
+ *                                           mismatch, so the roll-back path runs (results must not change)
+ *   hybrid_sync (CSIM_HYBRID_SYNC, 1)       see "Streams" above
+ *   dc_fast (CSIM_DC_FAST, 0)               DC operating points start on the fast generated kernel (FMA
+ *                                           contraction, reciprocal pivots; controller decisions within
+ *                                           its rounding noise are replayed) instead of the faithful one
  * Unknown key or bad value: CSIM_ERR_ARG.                                                        */
 int  csim_engine_set_option(csim_engine* eng, const char* key, const char* value);
+/* Counters of one engine since its creation (-1: unknown key).  Maintained in synchronous mode
+ * (hybrid_sync = 1) only:
+ *   "near_verified"      near-threshold convergence decisions of the fast transient kernels that the
+ *                        faithful kernel re-did (src/tanalisis.cpp:369; DESIGN.md "near-threshold guard")
+ *   "near_rolled_back"   of those, the ones whose pass count differed: the instance was rolled back      */
+int64_t csim_engine_stat(const csim_engine* eng, const char* key);
 
 /* Monte-Carlo parameter table on the device: instance b_first+i of the global
  * batch -> column i.  Instance 0 is the nominal circuit.  Counter-based:
