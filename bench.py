@@ -2,7 +2,10 @@
 """bench.py -- NR-iteration x instances / second of the batched transient solve.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1: either under a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (python -m
+    torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...), or bare: the process then
+    starts N child processes of itself, one per GPU, with that environment (it makes no GPU call of its own),
+    relays rank 0's JSON line and exits non-zero if any rank failed.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted
 on): tests/dbmixer.sp transient, B = 4096 Monte-Carlo-perturbed instances per
@@ -94,9 +97,60 @@ def valu_roof(units_per_s, counters, B, lanes_per_instance, flops_exec):
     return rec
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` started bare: one fresh child process per rank (nothing re-executes a process
+    that touched the GPU: this parent never imports torch).  Rank 0's stdout is relayed; every child's stderr
+    goes to ours.  Returns the exit status for the parent."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    # rank 0's stdout is drained by a thread so that the loop below can watch all ranks: when one fails the
+    # others would wait in a collective for ever, so they are stopped (the exact PIDs started here)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode("utf-8", "replace"))
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print("bench.py: ranks failed (rank, exit status): %s" % bad, file=sys.stderr)
+        return 1
+    return 0
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(nl, params_host, n_inst, tstep, n_tsteps, threads=1):
     """Oracle (CPU restatement) on a bounded sample of the same workload: instances 0..n_inst-1,
-    one instance per call, `threads` host threads over instances (the C call releases the GIL)."""
+    one instance per call, `threads` host threads over instances."""
     from oracle import binding as orc
 
     def one(b):
@@ -106,9 +160,10 @@ def cpu_baseline(nl, params_host, n_inst, tstep, n_tsteps, threads=1):
     if threads <= 1:
         iters = sum(one(b) for b in range(n_inst))
     else:
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(threads) as pool:
-            iters = sum(pool.map(one, range(n_inst)))
+        # POSIX threads inside the oracle library, one instance at a time from a shared counter (a Python thread
+        # pool of 256 ctypes callers spends its time on the interpreter lock: measured 7.7x on 256 cores)
+        per, _ = orc.tran_batch_mt(nl.ir_ptr, params_host, 0, n_inst, tstep, tstep * n_tsteps, threads)
+        iters = int(per.sum())
     dt = time.perf_counter() - t0
     return iters, dt
 
@@ -137,20 +192,28 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "general", "scheduled", "faithful"])
     ap.add_argument("--cpu-iters", type=float, default=3.0e6, help="approx. NR iterations of the CPU sample (~15 s)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the all-cores CPU leg (1 = skip it)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the all-cores CPU leg (0 = every core this process may run on; 1 = skip the leg)")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="target run time of the all-cores CPU leg")
+    ap.add_argument("--gen-opts", default="",
+                    help="re-generate the circuit's kernels with these generator options (engine option jit_gen_opts, "
+                         "e.g. near_band=0) before the run: A/B measurements of generator choices")
+    ap.add_argument("--async", dest="async_calls", action="store_true",
+                    help="engine option hybrid_sync=0: the transient calls only enqueue, the host never waits inside them")
     ap.add_argument("--large-batch", type=int, default=65536,
                     help="also time this many instances per GPU (one wave per SIMD needs >= 65536); 0 = skip")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # started bare: be the launcher (no GPU call in this process)
+        sys.exit(self_launch(args.gpus))
 
     import torch
     from circuitsimulator_amd import Engine, Netlist, shard
 
     rank, local_rank, world = shard.dist_env()
     if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
-                  file=sys.stderr)
-            sys.exit(2)
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the engine has no CPU path", file=sys.stderr)
         sys.exit(3)
@@ -178,6 +241,12 @@ def main():
         eng.set_kernel(args.kernel)
     if args.lanes:
         eng.set_option("lanes_per_instance", args.lanes)
+    if args.async_calls:
+        eng.set_option("hybrid_sync", 0)
+    if args.gen_opts and eng.tran_kernel != "general":
+        sched, dc_sched = eng.loaded_schedules()
+        eng.set_option("jit_gen_opts", args.gen_opts)
+        eng.jit_with_schedules(sched, dc_sched)
     N, B, S = nl.n_unknowns, args.batch, args.tsteps
     tstep = nl.tstep
 
@@ -229,10 +298,10 @@ def main():
 
     kern_ms = [a.elapsed_time(b) for a, b in ev]
     local_iters = int((iters - it_before).sum().item())
-    total_iters = shard.all_reduce_sum(float(local_iters), device=dev)
+    total_iters = shard.all_reduce_sum_int(local_iters, device=dev)          # int64
     wall_max = shard.all_reduce_max(wall, device=dev)
     n_bad = int((status & 0xA7).ne(0).sum().item())           # non-finite / non-converged / tiny pivot / fallback
-    n_bad = int(shard.all_reduce_sum(float(n_bad), device=dev))
+    n_bad = shard.all_reduce_sum_int(n_bad, device=dev)
 
     # ---- gather of node voltages (probes of the netlist: V(102), V(103)) -----
     t0 = time.perf_counter()
@@ -263,14 +332,14 @@ def main():
         torch.cuda.synchronize()
         shard.barrier()
         wl = shard.all_reduce_max(time.perf_counter() - t0, device=dev)
-        il = shard.all_reduce_sum(float((itl - before).sum().item()), device=dev)
+        il = shard.all_reduce_sum_int(int((itl - before).sum().item()), device=dev)
         large = {"batch_per_gpu": BL, "value": il / wl, "steps": nl_steps,
                  "kernel_avg_ms": e0.elapsed_time(e1) / nl_steps,
                  "flagged_instances": int((stl & 0xA7).ne(0).sum().item())}
         del pl, xl, itl, stl
 
     if args.dump_gathered and rank == 0:
-        np.savez(args.dump_gathered, gathered=all_v.cpu().numpy(), total_iters=total_iters)
+        np.savez(args.dump_gathered, gathered=all_v.cpu().numpy(), total_iters=np.int64(total_iters))
 
     if rank == 0:
         value = total_iters / wall_max
@@ -309,6 +378,7 @@ def main():
                 "lanes_per_instance": lanes,
                 "nr_iters_per_step": iters_per_launch,
                 "flagged_instances": n_bad, "refined_schedules": refined, "setup_probe_steps": probe_steps,
+                "generator_options": args.gen_opts,
             },
             # SURVEY.md 8(d) accounting: the bytes of the DENSE system the reference materialises per NR
             # iteration, 8(N^2+3N), not bytes this kernel moves (it keeps the sparse system on chip; what it
@@ -337,6 +407,9 @@ def main():
                 "achieved_tflops": (iters_per_launch / avg_kern_s) * dense_flops(nl.n_unknowns) / 1e12,
                 "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
             },
+            "dist_backend": shard.backend_name(),
+            "hybrid_sync": 0 if args.async_calls else 1,
+            "near_threshold": {"verified": eng.stat("near_verified"), "rolled_back": eng.stat("near_rolled_back")},
             "netlist_bcast_ms": bcast_ms,
             "result_gather_ms": gather_ms,
             "gathered_shape": list(all_v.shape),
@@ -355,7 +428,9 @@ def main():
         if world == 1 and not args.no_cpu:
             # CPU baseline: the oracle (port of the reference algorithm), 1 thread,
             # on the first instances of the same parameter table
-            ph = params[:, :256].cpu().numpy()
+            ncores = len(os.sched_getaffinity(0))
+            nthr = ncores if args.cpu_threads <= 0 else max(1, min(ncores, args.cpu_threads))
+            ph = params[:, :min(B, max(256, 64 * nthr))].cpu().numpy()
             s_cpu = min(S * args.steps, 2000)                  # bounded sample: at most 2000 time steps per instance
             est_per_inst = 10.0 * s_cpu
             n_cpu = int(max(1, min(ph.shape[1], round(args.cpu_iters / est_per_inst))))
@@ -365,18 +440,21 @@ def main():
                 "unit": "NR-iter*inst/s",
                 "cores": 1,
                 "kind": "port",
+                "cpu_model": cpu_model(),
                 "sample": "oracle/mna_oracle.c, instances 0..%d of the same table, %d time steps from the DC "
-                          "point (%d NR iterations, %.1f s, host has %d cores)"
-                          % (n_cpu - 1, s_cpu, ci, cdt, os.cpu_count() or 0),
+                          "point (%d NR iterations, %.1f s, host has %d cores, %d usable by this process)"
+                          % (n_cpu - 1, s_cpu, ci, cdt, os.cpu_count() or 0, ncores),
             }
-            # the same port on all host cores (threads over instances), a second bounded sample
-            nthr = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), args.cpu_threads))
+            # the same port on ALL host cores this process may run on (one thread per core over
+            # instances; the C call releases the GIL), a second bounded sample sized for ~cpu_seconds of wall time
             if nthr > 1:
-                n_mt = int(min(ph.shape[1], n_cpu * nthr))
+                per_inst_s = cdt / n_cpu
+                n_mt = int(max(nthr, min(ph.shape[1], round(args.cpu_seconds * nthr / per_inst_s))))
                 mi, mdt = cpu_baseline(nl, ph, n_mt, tstep, s_cpu, threads=nthr)
                 rec["cpu_baseline"]["all_cores"] = {
-                    "value": mi / mdt, "cores": nthr,
-                    "sample": "instances 0..%d, %d time steps (%d NR iterations, %.1f s)" % (n_mt - 1, s_cpu, mi, mdt),
+                    "value": mi / mdt, "cores": nthr, "host_cores": os.cpu_count() or 0,
+                    "sample": "instances 0..%d, %d time steps (%d NR iterations, %.1f s, %d threads)"
+                              % (n_mt - 1, s_cpu, mi, mdt, nthr),
                 }
         print(json.dumps(rec))
 

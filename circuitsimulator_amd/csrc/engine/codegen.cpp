@@ -615,6 +615,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
     else
         src << i2 << "bool active = live;\n"
             << i2 << "int it = 0;\n"
+            << (guard ? i2 + "double nearMin = 1.0;   // smallest |err - tol| of this step's passes\n" : std::string())
             << i2 << "for (int iter = 0; iter < " << K.tran_max_iters << "; ++iter) {\n"
             << i2 << "    if (!__any(active)) break;\n";
     // ---- per-iteration terms: MOS channel (device_common.hpp mos_eval)
@@ -953,22 +954,26 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         if (opt.faithful) o << g.ind << "        else if (iter == " << (K.tran_max_iters - 1) << ") st |= ST_TRAN_NONCONV;   // tanalisis.cpp:372-376\n";
         else o << g.ind << "        else if (iter >= " << (slowIters - 1) << ") { viol = true; active = false; }\n";
         if (guard)
-            // `err < tol` (tanalisis.cpp:369) decided within the rounding noise of this kernel's arithmetic: go on
-            // speculatively; the step's checkpoint is kept at the end of the step and the engine verifies the pass
-            // count with the faithful kernel.  One checkpoint per launch: a second such step stops the lane.
-            o << g.ind << "        if (fabs(err - " << lit(K.tran_tol) << ") <= " << lit(gopt.nearBand * K.tran_tol) << ") {\n"
-              << g.ind << "            if (nearS != 0 && nearS != (int)s) { viol = true; active = false; }\n"
-              << g.ind << "            else nearS = (int)s;\n"
-              << g.ind << "        }\n";
+            // near-threshold guard: how close did `err < tol` (tanalisis.cpp:369) come to a tie in this step?  Decided
+            // once per step, below.
+            o << g.ind << "        nearMin = fmin(nearMin, fabs(err - " << lit(K.tran_tol) << "));\n";
         o
           << g.ind << "    }\n"
           << g.ind << "}\n";
 
         src << g.out.str();
         src << i2 << "}\n"      // NR loop
+            << (guard
+                // `err < tol` decided within the rounding noise of this kernel's arithmetic: go on speculatively; the step's
+                // checkpoint is kept and the engine has the faithful kernel verify the pass count.  One checkpoint per
+                // launch: a second such step stops the lane at the start of that step.
+                ? i2 + "const bool nearEvent = live && !viol && nearMin <= " + lit(gopt.nearBand * K.tran_tol) + ";\n"
+                  + i2 + "viol = viol || (nearEvent && nearS != 0);\n"
+                : std::string())
             << i2 << "if (live && !viol) {\n"
             << (guard
-                ? i2 + "    if (nearS == (int)s) {     // xio still holds the state at the start of this step: keep it for the verification\n"
+                ? i2 + "    if (nearEvent) {     // xio still holds the state at the start of this step: keep it for the verification\n"
+                  + i2 + "        nearS = (int)s;\n"
                   + i2 + "        const double* ck = xio + b;\n" + i2 + "        double* nk = nearX + b;\n#pragma unroll 1\n"
                   + i2 + "        for (int i = 0; i < " + std::to_string(N) + "; ++i, ck += SB, nk += SB) *nk = *ck;\n"
                   + i2 + "        nearStep[b] = (int)s; nearIt[b] = it; nearItAfter[b] = itTotal;\n"
@@ -1038,10 +1043,20 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     // linear circuits: factor once per launch, substitute once per step (codegen_linear.cpp).  It replaces
     // the per-iteration kernels below for such circuits (they would re-factor in every Newton pass, and for
     // N = 257 cost minutes of compile time)
+    // Linear circuits first try the sixteen-lanes-per-instance form (tape, iterate and x_raw in registers); circuits
+    // whose tape does not fit the register file get the lane-per-instance form (iterate in LDS, tape streamed).
     int linWork = 0, linLanes = 0;
-    const std::string linSrc = emitLinearKernel(ir, ap, set.alts[0], &linWork, &linLanes);
-    const bool haveLinear = !linSrc.empty();
-    src << linSrc;
+    const std::string lin16Src = emitLinearGroupKernel(ir, ap, set.alts[0], &linWork);
+    const bool haveLinear16 = !lin16Src.empty();
+    const std::string linSrc = haveLinear16 ? std::string() : emitLinearKernel(ir, ap, set.alts[0], &linWork, &linLanes);
+    const bool haveLinear = haveLinear16 || !linSrc.empty();
+    // the sixteen-lanes-per-instance transient kernel of Newton circuits (group_plan.hpp): one solve body per schedule
+    // over the first one's row placement; a sequence none of them covers is a violation and goes through the ladder
+    GroupPlan groupPlan;
+    const std::string groupSrc = haveLinear ? std::string() : emitGroupKernel(ir, ap, set.alts, gopt, &groupPlan);
+    const bool haveGroup = !groupSrc.empty();
+    if (haveLinear16 || haveGroup) src << groupPreludeSource(ir);
+    src << lin16Src << linSrc;
 
     const int leanBudget = 80 - N;
     // a variant is emitted only if its LDS image fits one CU (163 840 B)
@@ -1108,11 +1123,6 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     }
     const bool haveDc = ldsDc >= 0;
 
-    // sixteen lanes per instance (group_plan.hpp): one solve body per schedule over the first one's row
-    // placement; a sequence none of them covers is a violation and goes through the hybrid stepping
-    GroupPlan groupPlan;
-    const std::string groupSrc = emitGroupKernel(ir, ap, set.alts, gopt, &groupPlan);
-    const bool haveGroup = !groupSrc.empty();
     src << groupSrc;
 
     char hbuf[32];
@@ -1136,7 +1146,9 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "// 1 when this library carries csim_tran_faithful_kernel (csim_sched_launch variant 3)\n"
         << "extern \"C\" int csim_sched_has_faithful(void) { return " << (haveFaithful ? 1 : 0) << "; }\n"
         << "// 16 when this library also carries csim_tran_group_kernel (sixteen lanes per instance, one solve body per schedule)\n"
-        << "extern \"C\" int csim_sched_group_lanes(void) { return " << (haveGroup ? 16 : 0) << "; }\n";
+        << "extern \"C\" int csim_sched_group_lanes(void) { return " << (haveGroup ? 16 : 0) << "; }\n"
+        << "// lanes per instance of the linear-circuit kernel: 16 (registers), 1 (LDS + streamed tape), 0 (not a linear circuit)\n"
+        << "extern \"C\" int csim_sched_linear_lanes(void) { return " << (haveLinear16 ? 16 : (haveLinear ? 1 : 0)) << "; }\n";
     src << ""
         << "// the recorded alternatives, [n_alts][N] pivot row positions (the engine hands them to the\n"
         << "// general kernel so that it can tell when an instance is back on a known sequence)\n"
@@ -1190,7 +1202,15 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "    const bool rich = " << (haveRich ? "(variant == 2)" : "false") << ";\n"
         ;
     src << "    (void)work;\n";
-    if (haveLinear)
+    if (haveLinear16)
+        src << "    if (work) {   // linear circuit: factor once per launch (lane per instance), then the time steps (16 lanes per instance)\n"
+            << "        hipLaunchKernelGGL(csim_lin16_factor_kernel, dim3(waves), dim3(64), 0, (hipStream_t)stream,\n"
+            << "                           params, B, dt, nSteps, outStride, aux->done, aux->fallback, work);\n"
+            << "        hipLaunchKernelGGL(csim_tran_linear16_kernel, dim3((unsigned)((B + 3) / 4)), dim3(64), 0, (hipStream_t)stream,\n"
+            << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
+            << "                           stepIters, aux->fallback, aux->done, aux->flags, work);\n"
+            << "        return (int)hipGetLastError();\n    }\n";
+    else if (haveLinear)
         src << "    if (work) {   // linear circuit: factor once per launch, substitute once per step\n"
             << "        hipLaunchKernelGGL(csim_tran_linear_kernel, dim3((unsigned)((B + " << linLanes - 1 << ") / " << linLanes << ")), dim3(" << linLanes << "), 0, (hipStream_t)stream,\n"
             << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"

@@ -84,7 +84,7 @@ struct GeneratorOptions {
 };
 
 // bumped whenever the emitted code or the launcher ABI of a generated library changes
-constexpr int kGeneratorRevision = 24;
+constexpr int kGeneratorRevision = 25;
 
 // identifies (topology, constants, schedule); names the generated library
 uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch);
@@ -99,6 +99,11 @@ struct CodegenStats {
 // per instance of the factor store the launcher needs, lanesPerWave = instances per workgroup.
 std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sc,
                              int* workDoubles, int* lanesPerWave);
+
+// codegen_linear.cpp: the same for SIXTEEN lanes per instance with iterate, x_raw and the factor tape in registers
+// (kernels csim_lin16_factor_kernel + csim_tran_linear16_kernel; needs groupPreludeSource() in front); "" when the
+// circuit has MOSFETs or its tape does not fit the register file.  workDoubles: doubles per instance of the tape.
+std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sc, int* workDoubles);
 
 // complete .hip translation unit: kernel + extern "C" launcher + metadata
 std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, const ScheduleSet& set,

@@ -154,6 +154,16 @@ __device__ __forceinline__ void grp_mos_eval(double p, double Vth, double K, dou
 
 } // namespace
 
+std::string groupPreludeSource(const csim_ir& ir)
+{
+    std::ostringstream o;
+    o << "#define GRP_WAVE_SIN " << CSIM_WAVE_SIN << "\n#define GRP_WAVE_PULSE " << CSIM_WAVE_PULSE << "\n#define GRP_WAVE_PWL " << CSIM_WAVE_PWL << "\n"
+      << "// outcome of one solve's pivot checks (see the first column of the elimination)\n"
+      << "#define GRP_PIVOTS_BAD (worst > (0x1.0000000000008p+0) || tie >= 0.0 || pmin < " << lit(ir.k.lu_eps) << ")\n"
+      << kPrelude << "\n";
+    return o.str();
+}
+
 std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std::vector<PivotSchedule>& schedules,
                             const GeneratorOptions& gopt, GroupPlan* planOut)
 {
@@ -189,11 +199,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     const int instDoubles = oST + (nStage + 1) * G;
     if (instDoubles * 8 * 4 > 64 * 1024) return std::string();  // keep 2+ waves per CU possible; larger circuits: no group kernel
 
-    std::ostringstream o;
-    o << "#define GRP_WAVE_SIN " << CSIM_WAVE_SIN << "\n#define GRP_WAVE_PULSE " << CSIM_WAVE_PULSE << "\n#define GRP_WAVE_PWL " << CSIM_WAVE_PWL << "\n"
-      << "// outcome of one solve's pivot checks (see the first column of the elimination)\n"
-      << "#define GRP_PIVOTS_BAD (worst > (0x1.0000000000008p+0) || tie >= 0.0 || pmin < " << lit(ir.k.lu_eps) << ")\n"
-      << kPrelude << "\n";
+    std::ostringstream o;      // (the shared device code, groupPreludeSource(), is emitted by the caller)
 
     // ---- circuit tables
     {
@@ -437,7 +443,8 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     const int slowIters = slowStepIters(K.tran_tol, K.tran_alpha, K.tran_max_iters);
     const std::string in = "            ";
     o << "        bool active = live;\n"
-      << "        int it = 0;\n";
+      << "        int it = 0;\n"
+      << (guard ? "        double nearMin = 1.0;   // smallest |err - tol| of this step's passes\n" : "");
     o << "        for (int iter = 0; iter < " << K.tran_max_iters << "; ++iter) {\n"
       << "            if (!__any(active)) break;\n";
     if (!piped) emitMos(in);
@@ -662,18 +669,16 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
       << in << "const bool conv = err < " << lit(K.tran_tol) << ";\n"
       << in << "const bool slow = !conv && iter >= " << (slowIters - 1) << ";                 // slow step: plan.hpp slowStepIters\n";
     if (guard)
-        // `err < tol` (tanalisis.cpp:369) decided within the rounding noise of this kernel's arithmetic: the group goes on
-        // speculatively, the step's start state is kept at the end of the step, and the engine verifies the pass count
-        // with the faithful kernel.  One checkpoint per launch: a second such step stops the group.
-        o << in << "const bool near = good && fabs(err - " << lit(K.tran_tol) << ") <= " << lit(gopt.nearBand * K.tran_tol) << ";\n"
-          << in << "const bool again = near && nearS != 0 && nearS != (int)s;\n"
-          << in << "nearS = (near && nearS == 0) ? (int)s : nearS;\n";
-    o << in << "viol = viol || (active && !good) || (good && slow)" << (guard ? " || again" : "") << ";\n"
+        // near-threshold guard: how close did `err < tol` (tanalisis.cpp:369) come to a tie in this step?  Two
+        // instructions per pass; everything else happens once per step, below.  (Passes after a group has converged
+        // are included: they can only raise a false alarm, which costs a verification and changes nothing.)
+        o << in << "nearMin = fmin(nearMin, fabs(err - " << lit(K.tran_tol) << "));\n";
+    o << in << "viol = viol || (active && !good) || (good && slow);\n"
       << in << "it += good ? 1 : 0;\n";
     for (int s = 0; s < S; ++s) o << in << "xo" << s << " = good ? xn" << s << " : xo" << s << ";\n";
     // the empty asm pins the loads of the next iteration's MOSFET inputs (and staging rows) to this side of the loop's
     // back edge (the compiler otherwise sinks them to the head of the next iteration, in front of what needs them)
-    o << in << "active = good && !conv && !slow" << (guard ? " && !again" : "") << ";\n"
+    o << in << "active = good && !conv && !slow;\n"
       << in << "__builtin_amdgcn_sched_barrier(0);\n";
     if (piped) {
         for (int r0 = 0; r0 < nStage; r0 += 12) {
@@ -687,9 +692,17 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     }
     o
       << "        }\n"      // NR loop
-      << "        if (live && !viol) {\n";
+      ;
+    if (guard)
+        // `err < tol` decided within the rounding noise of this kernel's arithmetic: the group goes on speculatively, the
+        // step's start state is kept, and the engine has the faithful kernel verify the step's pass count afterwards.
+        // One checkpoint per launch: a second such step stops the group at the start of that step.
+        o << "        const bool nearEvent = live && !viol && nearMin <= " << lit(gopt.nearBand * K.tran_tol) << ";\n"
+          << "        viol = viol || (nearEvent && nearS != 0);\n";
+    o << "        if (live && !viol) {\n";
     if (guard) {
-        o << "            if (nearS == (int)s) {     // keep the state at the start of this step for the verification\n";
+        o << "            if (nearEvent) {           // keep the state at the start of this step for the verification\n"
+          << "                nearS = (int)s;\n";
         for (int s = 0; s < S; ++s)
             o << "                if (" << s * G << " + g < " << N << ") nearX[(long long)(" << s * G << " + g) * SB + b] = XP[" << s * G << " + g];\n";
         o << "                if (g == 0) { nearStep[b] = (int)s; nearIt[b] = it; nearItAfter[b] = itTotal; }\n"

@@ -18,10 +18,19 @@
 //   * per Newton pass executes what remains of the reference's loop body: the damped update
 //     x += alpha (x_raw - x), the norm in index order and the convergence test (:365-376).  Pass counts
 //     are executed, not predicted.
-// One lane owns one instance (iterate and x_raw in LDS, lane-private columns).  Same deliberate
-// floating-point differences as the other generated kernels: FMA contraction, one Newton-refined
-// reciprocal per pivot.  Round 1 got the factorisation out of the loops only through hipcc's
-// loop-invariant code motion, at 13 KB of scratch per lane; this kernel needs none.
+// The arithmetic is the REFERENCE's: no FMA contraction, one true division per multiplier
+// (solver.hpp:71), a correctly rounded division per solution entry (:126; formed from the parked pivot and
+// its correctly rounded reciprocal with one residual correction, the sequence the compiler's own f64
+// division ends with), sums in the reference's order -- so on a recorded pivot sequence these kernels
+// perform the reference's operations and there is no near-threshold hole to guard (codegen.hpp).  The one
+// liberty: the 2-norm of the damped step is summed lane-locally and then across the lanes of a group
+// (sixteen-lane kernel), not in index order; it feeds the `err < tol` threshold only.
+//
+// Two kernels share the symbolic factorisation (buildLinearFactor):
+//   csim_tran_linear16_kernel (+ csim_lin16_factor_kernel)  SIXTEEN lanes per instance, iterate, x_raw
+//       and the whole tape in registers (emitLinearGroupKernel below) -- BASELINE configs[3];
+//   csim_tran_linear_kernel   one lane per instance, iterate and x_raw in LDS, tape streamed from global
+//       memory -- circuits whose tape does not fit the register file (N = 601 ladder of the tests).
 #include "codegen.hpp"
 
 #include <algorithm>
@@ -83,6 +92,16 @@ struct LGen {
         }
         LV r = emit(a.e + " * " + b.e);
         r.neg = a.neg != b.neg;
+        return r;
+    }
+    LV div(const LV& a, const LV& b)                     // a / b, a true division (solver.hpp:71)
+    {
+        if (a.zero()) return LV();
+        if (a.kind == LV::CONST && b.kind == LV::CONST) return LV::konst(a.c / b.c);
+        if (b.kind == LV::CONST && b.c == 1.0) return a;
+        if (b.kind == LV::CONST && b.c == -1.0) return negate(a);
+        LV r = emit((a.kind == LV::CONST ? lit(a.c) : a.e) + " / " + (b.kind == LV::CONST ? lit(b.c) : b.e));
+        r.neg = (a.kind == LV::DYN && a.neg) != (b.kind == LV::DYN && b.neg);
         return r;
     }
     LV fnma(const LV& a, const LV& f, const LV& u)      // a - f*u
@@ -182,46 +201,76 @@ void emitTranSourceValue(std::ostream& src, const std::string& i2, const csim_ir
     }
 }
 
-// Emits csim_tran_linear_kernel.  workDoubles = doubles per instance of the factor store the launcher
-// must be given; lanesPerWave = instances per workgroup (iterate + x_raw must fit one CU's LDS).
-std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sc,
-                             int* workDoubles, int* lanesPerWave)
+namespace {
+
+// device helpers shared by both linear kernels (emitted once per generated library)
+std::string linearPrelude()
+{
+    static bool dummy = false;
+    (void)dummy;
+    return "#ifndef CSIM_LIN_PRELUDE\n#define CSIM_LIN_PRELUDE\n"
+           "#pragma clang fp contract(off)\n"
+           "__device__ __forceinline__ double lin_ginv(double R) { return (R == 0.0) ? 0.0 : 1.0 / R; }            // element.cpp:20-24\n"
+           "__device__ __forceinline__ double lin_gc(double C, double dt) { return (C > 0.0 && dt > 0.0) ? C / dt : 0.0; }   // tanalisis.cpp:65-67\n"
+           "// s / p from p and r = the correctly rounded 1 / p (see codegen_linear.cpp emitQuotient)\n"
+           "__device__ __forceinline__ double lin_quot(double s, double p, double r)\n{\n"
+           "    const double q0 = s * r;\n    const double e = fma(-p, q0, s);\n    return fma(e, r, q0);\n}\n"
+           "#pragma clang fp contract(fast)\n#endif\n";
+}
+
+// Operands that a per-step block takes from the factor block travel over the "tape".  While the code is
+// generated they are placeholders: "@L<h>@" where handle h is read, "@S<h>@" where its value (the local
+// `pk`) is stored, "@F<h>|<expr>@" where the factor block itself reads a launch constant back.  A back-end
+// numbers the reads (tape positions) and resolveFactorText() stores every handle to all positions that read it.
+std::string rdHandle(int h) { return "@L" + std::to_string(h) + "@"; }
+int handleOf(const LV& v)          // handle of a parked run-time value, -1 for anything else
+{
+    if (v.kind != LV::DYN || v.e.size() < 4 || v.e.compare(0, 2, "@L") != 0) return -1;
+    return std::atoi(v.e.c_str() + 2);
+}
+
+struct FwdOp { int i, k; LV f; };              // b_i -= f * b_k, row positions at that point of the elimination
+
+// Symbolic factorisation of a linear circuit's transient matrix with the recorded pivots, shared by both
+// linear kernels.  `text` is device code for ONE lane = one instance (it expects params, SB, bb, vo0, dt,
+// viol, and the macros TW / TF): launch constants, then assembly (lazy) + elimination with the reference's
+// arithmetic, every pivot choice verified (flag pvF).
+struct LinearFactor {
+    int nHandles = 0;
+    std::string text;
+    std::vector<FwdOp> fwd;
+    std::vector<int> swapWith;                  // row swap of column k (position), in order
+    std::vector<std::vector<LV>> U;             // finished rows: U[k][j], j > k
+    std::vector<LV> piv, rinv;                  // U(k,k) and its correctly rounded reciprocal
+    std::vector<int> coefHandle;                // per element: handle of C/dt (capacitor) or L/dt (inductor), else -1
+};
+
+void buildLinearFactor(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sc, LinearFactor& F)
 {
     const int N = ir.n_unknowns;
     const csim_consts& K = ir.k;
-    if (ir.has_nonlinear || N <= 0) return std::string();
-    int LPW = 64;
-    while (LPW >= 8 && 2LL * N * 8 * LPW > 160 * 1024) LPW /= 2;
-    if (LPW < 8) return std::string();
     const int LD = ap.LD;
     const GatherPlan& gpl = ap.tran;
-
-    // Operands that the per-step block takes from the factor block travel over the tape.  While the code is
-    // generated they are placeholders: "@L<h>@" where handle h is read, "@S<h>@" where its value (the local
-    // `pk`) is stored.  Afterwards the reads are numbered in the order in which they appear in the per-step
-    // block and every handle is stored to all the positions that read it.
-    int nHandles = 0;
-    auto rd = [](int h) { return "@L" + std::to_string(h) + "@"; };
+    int& nHandles = F.nHandles;
+    auto rd = rdHandle;
     auto st = [](int h) { return "@S" + std::to_string(h) + "@"; };
+    F.coefHandle.assign(static_cast<std::size_t>(ir.n_elems), -1);
     // "@F<h>|<expr>@": the factor block's read of a launch constant -- from the tape where the step reads it too
     // (its first slot), else <expr>.  Recomputing it from params there made hipcc keep the parameter's ADDRESS
     // from the first read alive across the whole factor block: 631 spilled addresses, a 4.9 KB scratch frame.
     auto rdF = [](int h, const std::string& expr) { return "@F" + std::to_string(h) + "|" + expr + "@"; };
     // ---- terms.  Launch constants are written to the store once (factor block) and re-read where needed.
-    std::vector<LV> termF(static_cast<std::size_t>(ap.nTerms)), termS(static_cast<std::size_t>(ap.nTerms));
+    std::vector<LV> termF(static_cast<std::size_t>(ap.nTerms));
     std::ostringstream consts;                            // code that fills the launch constants
     int nConstStmts = 0;                                  // a scheduling barrier every 16: see the factor block
-    std::ostringstream stepCode;                          // per-step source values
-    termF[static_cast<std::size_t>(ap.termOne)] = termS[static_cast<std::size_t>(ap.termOne)] = LV::konst(1.0);
-    termF[static_cast<std::size_t>(ap.termGmin)] = termS[static_cast<std::size_t>(ap.termGmin)] = LV::konst(K.tran_gmin);
+    termF[static_cast<std::size_t>(ap.termOne)] = LV::konst(1.0);
+    termF[static_cast<std::size_t>(ap.termGmin)] = LV::konst(K.tran_gmin);
     auto PX = [](int slot) { return "params[" + std::to_string(slot) + "LL * SB + bb]"; };
     // the same parameter as read by the factor block: through an always-zero offset the compiler cannot fold, so that
     // it does not keep all C/dt of the tape-filling block alive (in scratch) for the factor block's matrix entries
     auto PF = [](int slot) { return "params[" + std::to_string(slot) + "LL * SB + bb + vo0]"; };
     for (int e = 0; e < ir.n_elems; ++e) {
         const int s = ir.param_slot[e], tb = ap.termBase[static_cast<std::size_t>(e)];
-        const int32_t* q = ir.eq + 4 * e;
-        auto X = [&](int eq) { return eq >= 0 ? "XL(" + std::to_string(eq) + ")" : std::string("0.0"); };
         switch (ir.kind[e]) {
             case CSIM_R:
                 // used by the factorisation only (once per launch): evaluated where a G entry needs it
@@ -229,33 +278,19 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
                 break;
             case CSIM_C: {
                 const int h = nHandles++;
+                F.coefHandle[static_cast<std::size_t>(e)] = h;
                 consts << "    { const double pk = lin_gc(" << PX(s) << ", dt); " << st(h) << " }\n";
                 if ((++nConstStmts % 16) == 0) consts << "    __builtin_amdgcn_sched_barrier(0);\n";
                 termF[static_cast<std::size_t>(tb + T_C_GC)] = LV::dyn(rdF(h, "lin_gc(" + PF(s) + ", dt)"));
-                // history current -Gc * vPrev (tanalisis.cpp:77), evaluated where the right-hand side needs it:
-                // the substitution runs at the start of the step, when XL still holds the previous state
-                const std::string v = (q[0] >= 0 && q[1] >= 0) ? "(" + X(q[0]) + " - " + X(q[1]) + ")"
-                                      : (q[0] >= 0 ? X(q[0]) : (q[1] >= 0 ? "(-" + X(q[1]) + ")" : std::string("0.0")));
-                termS[static_cast<std::size_t>(tb + T_C_IH)] = LV::dyn("(-" + rd(h) + " * " + v + ")");
                 break;
             }
             case CSIM_L: {
                 const int h = nHandles++;
+                F.coefHandle[static_cast<std::size_t>(e)] = h;
                 consts << "    { const double L = " << PX(s) << "; viol = viol || !(L > 0.0); const double pk = L / dt; " << st(h) << " }\n";
                 if ((++nConstStmts % 16) == 0) consts << "    __builtin_amdgcn_sched_barrier(0);\n";
                 termF[static_cast<std::size_t>(tb + T_L_REQ)] = LV::dyn(rdF(h, "(" + PF(s) + " / dt)"));
                 termF[static_cast<std::size_t>(tb + T_L_ONE)] = LV::konst(1.0);
-                const int kb = ir.branch_eq[e];
-                termS[static_cast<std::size_t>(tb + T_L_VH)] = LV::dyn("(-" + rd(h) + " * " + X((kb >= 0 && kb < N) ? kb : -1) + ")");
-                break;
-            }
-            case CSIM_V: case CSIM_I: {
-                const std::string name = "sv" + std::to_string(e);
-                stepCode << "        double " << name << ";\n";
-                // parameters are re-read per step through an offset the compiler cannot fold (see codegen.cpp)
-                emitTranSourceValue(stepCode, "        ", ir, e,
-                                    [&](int o) { return "params[" + std::to_string(s + o) + "LL * SB + bb + vo]"; }, name);
-                termS[static_cast<std::size_t>(tb + T_SRC_VAL)] = LV::dyn(name);
                 break;
             }
             default: break;
@@ -293,10 +328,12 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
         gf.out << gf.ind << "{ const double pk = " << gf.ref(v) << "; " << st(h) << " }\n";
         return LV::dyn(rd(h));
     };
-    struct FwdOp { int i, k; LV f; };
-    std::vector<FwdOp> fwd;                                // b_i -= f * b_k, in elimination order
-    std::vector<int> swapWith(static_cast<std::size_t>(N));
-    std::vector<LV> rinv(static_cast<std::size_t>(N));
+    std::vector<FwdOp>& fwd = F.fwd;                       // b_i -= f * b_k, in elimination order
+    std::vector<int>& swapWith = F.swapWith;
+    swapWith.assign(static_cast<std::size_t>(N), 0);
+    std::vector<LV>& rinv = F.rinv;
+    rinv.assign(static_cast<std::size_t>(N), LV());
+    F.piv.assign(static_cast<std::size_t>(N), LV());
     for (int k = 0; k < N; ++k) {
         const int p = sc.pivotPos[static_cast<std::size_t>(k)];
         swapWith[static_cast<std::size_t>(k)] = p;
@@ -339,13 +376,13 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
         }
         if (p != k) { std::swap(M[static_cast<std::size_t>(p)], M[static_cast<std::size_t>(k)]); std::swap(pend[static_cast<std::size_t>(p)], pend[static_cast<std::size_t>(k)]); }
         const LV piv = at(k, k);
-        LV r;
+        LV r;                                                             // correctly rounded 1 / pivot (for :126)
         if (piv.kind == LV::CONST) r = LV::konst(1.0 / piv.c);
-        else if (piv.kind == LV::DYN) r = gf.emit("rcp_nr(" + gf.ref(piv) + ")");
+        else if (piv.kind == LV::DYN) r = gf.emit("1.0 / " + gf.ref(piv));
         for (int i = k + 1; i < N; ++i) {
             const LV aik = at(i, k);
             if (aik.zero()) continue;
-            const LV f = gf.mul(aik, r);                                  // multiplier (solver.hpp:71)
+            const LV f = gf.div(aik, piv);                                // multiplier, a true division (solver.hpp:71)
             for (int j = k + 1; j < N; ++j) {
                 if (M[static_cast<std::size_t>(k)][static_cast<std::size_t>(j)].zero()) continue;
                 const LV u = at(k, j);
@@ -362,6 +399,116 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
             M[static_cast<std::size_t>(k)][static_cast<std::size_t>(j)] = park(at(k, j));
         }
         rinv[static_cast<std::size_t>(k)] = park(r);
+        F.piv[static_cast<std::size_t>(k)] = park(piv);
+    }
+    F.U = M;
+    F.text = consts.str() + "    // factorisation, once per launch: G does not depend on the iterate or on time\n    int pvF = 0;\n" + gf.out.str();
+}
+
+// every handle is stored to all the tape positions that read it; the factor block's own reads of launch
+// constants come from the tape where a step reads them too (first position), else from their expression
+std::string resolveFactorText(std::string factorText, const std::vector<std::vector<int>>& uses)
+{
+    std::string outText;
+    std::size_t i = 0;
+    while (i < factorText.size()) {
+        const std::size_t a = factorText.find("@S", i);
+        if (a == std::string::npos) { outText += factorText.substr(i); break; }
+        const std::size_t b = factorText.find('@', a + 2);
+        const int h = std::atoi(factorText.substr(a + 2, b - a - 2).c_str());
+        outText += factorText.substr(i, a - i);
+        for (int n : uses[static_cast<std::size_t>(h)]) outText += "TW(" + std::to_string(n) + ") = pk; ";
+        i = b + 1;
+    }
+    factorText = outText;
+    outText.clear();
+    i = 0;
+    while (i < factorText.size()) {
+        const std::size_t a = factorText.find("@F", i);
+        if (a == std::string::npos) { outText += factorText.substr(i); break; }
+        const std::size_t bar = factorText.find('|', a + 2), b = factorText.find('@', bar + 1);
+        const int h = std::atoi(factorText.substr(a + 2, bar - a - 2).c_str());
+        outText += factorText.substr(i, a - i);
+        if (!uses[static_cast<std::size_t>(h)].empty()) outText += "TF(" + std::to_string(uses[static_cast<std::size_t>(h)][0]) + ")";
+        else outText += factorText.substr(bar + 1, b - bar - 1);
+        i = b + 1;
+    }
+    return outText;
+}
+
+// x = sum / U(i,i) (solver.hpp:126) from the parked pivot and its correctly rounded reciprocal: q0 = sum * r,
+// e = sum - piv * q0 (exact, one FMA), q = q0 + e * r -- the last three steps of the compiler's own f64 division
+// (which refines v_rcp_f64 first); with r correctly rounded the quotient is the correctly rounded one.
+// (tools/dev/ubench/div_markstein.hip compares it with the `/` operator.)
+LV emitQuotient(LGen& g, const LV& sum, const LV& piv, const LV& rinv)
+{
+    if (sum.zero()) return LV();
+    if (piv.kind == LV::CONST) {
+        if (piv.c == 1.0) return sum;
+        if (piv.c == -1.0) return g.negate(sum);
+        return g.emit(g.ref(sum) + " / " + lit(piv.c));
+    }
+    const std::string n = g.prefix + std::to_string(g.tmp++);
+    g.out << g.ind << "const double " << n << " = lin_quot(" << g.ref(sum) << ", " << g.ref(piv) << ", " << g.ref(rinv) << ");\n";
+    return LV::dyn(n);
+}
+
+} // namespace
+
+// Emits csim_tran_linear_kernel.  workDoubles = doubles per instance of the factor store the launcher
+// must be given; lanesPerWave = instances per workgroup (iterate + x_raw must fit one CU's LDS).
+std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sc,
+                             int* workDoubles, int* lanesPerWave)
+{
+    const int N = ir.n_unknowns;
+    const csim_consts& K = ir.k;
+    if (ir.has_nonlinear || N <= 0) return std::string();
+    int LPW = 64;
+    while (LPW >= 8 && 2LL * N * 8 * LPW > 160 * 1024) LPW /= 2;
+    if (LPW < 8) return std::string();
+    const GatherPlan& gpl = ap.tran;
+    LinearFactor F;
+    buildLinearFactor(ir, ap, sc, F);
+    const int nHandles = F.nHandles;
+    const std::vector<FwdOp>& fwd = F.fwd;
+    const std::vector<int>& swapWith = F.swapWith;
+    const std::vector<std::vector<LV>>& M = F.U;
+    auto rd = rdHandle;
+    // per-step terms: sources evaluated at tNow, history currents from the previous state (still in XL when the
+    // substitution runs, at the start of the step)
+    std::vector<LV> termS(static_cast<std::size_t>(ap.nTerms));
+    std::ostringstream stepCode;
+    termS[static_cast<std::size_t>(ap.termOne)] = LV::konst(1.0);
+    termS[static_cast<std::size_t>(ap.termGmin)] = LV::konst(K.tran_gmin);
+    for (int e = 0; e < ir.n_elems; ++e) {
+        const int s = ir.param_slot[e], tb = ap.termBase[static_cast<std::size_t>(e)];
+        const int32_t* q = ir.eq + 4 * e;
+        auto X = [&](int eq) { return eq >= 0 ? "XL(" + std::to_string(eq) + ")" : std::string("0.0"); };
+        const int h = F.coefHandle[static_cast<std::size_t>(e)];
+        switch (ir.kind[e]) {
+            case CSIM_C: {
+                // history current -Gc * vPrev (tanalisis.cpp:77)
+                const std::string v = (q[0] >= 0 && q[1] >= 0) ? "(" + X(q[0]) + " - " + X(q[1]) + ")"
+                                      : (q[0] >= 0 ? X(q[0]) : (q[1] >= 0 ? "(-" + X(q[1]) + ")" : std::string("0.0")));
+                termS[static_cast<std::size_t>(tb + T_C_IH)] = LV::dyn("(-" + rd(h) + " * " + v + ")");
+                break;
+            }
+            case CSIM_L: {
+                const int kb = ir.branch_eq[e];
+                termS[static_cast<std::size_t>(tb + T_L_VH)] = LV::dyn("(-" + rd(h) + " * " + X((kb >= 0 && kb < N) ? kb : -1) + ")");
+                break;
+            }
+            case CSIM_V: case CSIM_I: {
+                const std::string name = "sv" + std::to_string(e);
+                stepCode << "        double " << name << ";\n";
+                // parameters are re-read per step through an offset the compiler cannot fold (see codegen.cpp)
+                emitTranSourceValue(stepCode, "        ", ir, e,
+                                    [&](int o) { return "params[" + std::to_string(s + o) + "LL * SB + bb + vo]"; }, name);
+                termS[static_cast<std::size_t>(tb + T_SRC_VAL)] = LV::dyn(name);
+                break;
+            }
+            default: break;
+        }
     }
 
     // ---- per-step block: right-hand side, forward elimination replayed, back substitution
@@ -408,14 +555,14 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
             if (u.zero()) continue;
             sum = gs.fnma(sum, u, xr[static_cast<std::size_t>(j)]);
         }
-        LV x = gs.mul(sum, rinv[static_cast<std::size_t>(i)]);
+        LV x = emitQuotient(gs, sum, F.piv[static_cast<std::size_t>(i)], F.rinv[static_cast<std::size_t>(i)]);
         if (x.kind == LV::DYN && (x.e.compare(0, 2, "vs") != 0 || x.neg)) x = gs.emit(gs.ref(x));    // a named value, read once below
         gs.out << gs.ind << "XRL(" << i << ") = " << gs.ref(x) << ";\n";
         xr[static_cast<std::size_t>(i)] = x;
     }
 
     // ---- number the tape in the order of the per-step block's reads
-    std::string stepText = gs.out.str(), factorText = consts.str() + "    // factorisation, once per launch: G does not depend on the iterate or on time\n    int pvF = 0;\n" + gf.out.str();
+    std::string stepText = gs.out.str();
     std::vector<std::vector<int>> uses(static_cast<std::size_t>(nHandles));
     int nTape = 0;
     {
@@ -431,32 +578,8 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
             i = b + 1;
         }
         stepText = outText;
-        outText.clear();
-        i = 0;
-        while (i < factorText.size()) {
-            const std::size_t a = factorText.find("@S", i);
-            if (a == std::string::npos) { outText += factorText.substr(i); break; }
-            const std::size_t b = factorText.find('@', a + 2);
-            const int h = std::atoi(factorText.substr(a + 2, b - a - 2).c_str());
-            outText += factorText.substr(i, a - i);
-            for (int n : uses[static_cast<std::size_t>(h)]) outText += "TW(" + std::to_string(n) + ") = pk; ";
-            i = b + 1;
-        }
-        factorText = outText;
-        outText.clear();
-        i = 0;
-        while (i < factorText.size()) {
-            const std::size_t a = factorText.find("@F", i);
-            if (a == std::string::npos) { outText += factorText.substr(i); break; }
-            const std::size_t bar = factorText.find('|', a + 2), b = factorText.find('@', bar + 1);
-            const int h = std::atoi(factorText.substr(a + 2, bar - a - 2).c_str());
-            outText += factorText.substr(i, a - i);
-            if (!uses[static_cast<std::size_t>(h)].empty()) outText += "TF(" + std::to_string(uses[static_cast<std::size_t>(h)][0]) + ")";
-            else outText += factorText.substr(bar + 1, b - bar - 1);
-            i = b + 1;
-        }
-        factorText = outText;
     }
+    const std::string factorText = resolveFactorText(F.text, uses);
     // The step reads the tape strictly in order, one miss of ~700 cycles each if it waits for every entry
     // where it is used (measured: 454 us per step on the N = 257 ladder, 1539 sequential misses).  So the
     // entries are loaded into registers two chunks of 32 ahead of their use: loads of chunk c+2 are issued
@@ -505,12 +628,11 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
     }
     if (nTape == 0) nTape = 1;
 
-    const int slowIters = slowStepIters(K.tran_tol, K.tran_alpha, K.tran_max_iters);
     std::ostringstream o;
     o << "// ---- linear circuit: factor once per launch, substitute once per step (codegen_linear.cpp)\n"
-      << "__device__ __forceinline__ double lin_ginv(double R) { return (R == 0.0) ? 0.0 : 1.0 / R; }            // element.cpp:20-24\n"
-      << "__device__ __forceinline__ double lin_gc(double C, double dt) { return (C > 0.0 && dt > 0.0) ? C / dt : 0.0; }   // tanalisis.cpp:65-67\n"
+      << linearPrelude()
       << "// pivot schedule: " << (sc.str().empty() ? std::string("-") : sc.str()) << "\n"
+      << "#pragma clang fp contract(off)\n"
       << "extern \"C\" __global__ void __launch_bounds__(64)\n"
       << "csim_tran_linear_kernel(const double* __restrict__ params, int B, double dt, long long stepFirst,\n"
       << "                        long long nSteps, const int* __restrict__ probeEq, int nProbe, int outStride,\n"
@@ -591,7 +713,7 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
       << "                else {\n"
       << "                    ++it;\n"
       << "                    if (err < " << lit(K.tran_tol) << ") active = false;\n"
-      << "                    else if (iter >= " << (slowIters - 1) << ") { viol = true; active = false; }   // slow step: plan.hpp slowStepIters\n"
+      << "                    else if (iter == " << (K.tran_max_iters - 1) << ") st |= ST_TRAN_NONCONV;   // tanalisis.cpp:372-376 (kept, as upstream)\n"
       << "                }\n"
       << "            }\n"
       << "        }\n"
@@ -606,7 +728,7 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
       << "        }\n"
       << "    }\n"
       << "    if (inb) {\n"
-      << "        if (viol) { fallback[b] = 1; *violFlag = 1; }   // xio holds the checkpoint of the step that failed\n"
+      << "        if (viol) { fallback[b] = 1; violFlag[0] = 1; }   // xio holds the checkpoint of the step that failed\n"
       << "        else {\n"
       << "            double* xo = xio + b;\n#pragma unroll 1\n"
       << "            for (int i = 0; i < " << N << "; ++i, xo += SB) *xo = XL(i);\n"
@@ -615,10 +737,406 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
       << "        status[b] |= st;\n"
       << "        done[b] = (int)sdone;\n"
       << "    }\n"
-      << "#undef XL\n#undef XRL\n#undef TW\n#undef TP\n"
-      << "}\n\n";
+      << "#undef XL\n#undef XRL\n#undef TW\n#undef TP\n#undef TF\n"
+      << "}\n#pragma clang fp contract(fast)\n\n";
     if (workDoubles) *workDoubles = nTape;
     if (lanesPerWave) *lanesPerWave = LPW;
+    return o.str();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Sixteen lanes per instance (BASELINE configs[3], the N = 257 RC ladder).
+//
+// The lane-per-instance kernel above keeps iterate and x_raw in LDS (2 N doubles per lane: 32 lanes, ONE wave
+// per CU at N = 257) and re-reads its factor tape from global memory in every time step: measured round 2,
+// 4.8 % of VALU issue, 768 of 1024 SIMDs idle, 7-11 GB of HBM traffic per 100-step launch.  Here one instance
+// is a DPP row of 16 lanes, 4 instances per wavefront, and EVERYTHING a time step touches sits in registers:
+//   x[s], w[s]   lane g, slot s: unknown 16 s + g of the iterate / of the right-hand side that the substitution
+//                turns into x_raw in place (row of final pivot position p lives at lane p % 16, slot p / 16;
+//                x_j is formed in the pivot row of column j, i.e. in its own place);
+//   tp<r>        the factor tape: every parked value (multiplier, U entry, pivot, pivot reciprocal, C/dt) is
+//                stored in the lane that CONSUMES it, in the order in which that lane consumes them, so an
+//                operation reads its operand from the register file of the lane that executes it and only
+//                the substitution's running values (b_k, x_j) travel, by DPP row broadcast.
+// The substitution is a serial chain (the ladder is tridiagonal plus a border row), so one lane of sixteen
+// does useful work in each of its instructions: b_P -= f * b_k is  bcast(b_k); t = tp * bcast;
+// w = fma(-t, mk<P % 16>, w)  -- mk<t> is the per-lane 0/1 constant (g == t), t * 1 and t * 0 are exact, so the
+// owning lane performs the reference's rounded subtraction and the others keep their value (a lane's t is
+// its own unrelated tape entry times the broadcast: finite, or the instance is non-finite anyway and leaves
+// for the general kernel).  The damped passes -- 17 per step on the ladder, the bulk of the reference's
+// work -- are elementwise on registers, all lanes busy.  The factorisation runs once per launch in its own
+// lane-per-instance kernel (csim_lin16_factor_kernel, the straight-line block of buildLinearFactor) and
+// writes the tape to global memory in consumer order: [entry r][lane g][instance], read once per launch.
+std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sc, int* workDoubles)
+{
+    const int N = ir.n_unknowns, G = 16;
+    const csim_consts& K = ir.k;
+    if (ir.has_nonlinear || N <= 0) return std::string();
+    const int S = (N + G - 1) / G, NP = S * G;
+    const GatherPlan& gpl = ap.tran;
+    LinearFactor F;
+    buildLinearFactor(ir, ap, sc, F);
+    auto sz = [](int v) { return static_cast<std::size_t>(v); };
+
+    // ---- where rows end up: final pivot positions (the right-hand side is assembled there directly)
+    std::vector<int> cur(sz(N));
+    for (int i = 0; i < N; ++i) cur[sz(i)] = i;
+    std::vector<int> opOrig(F.fwd.size());
+    {
+        std::size_t op = 0;
+        for (int k = 0; k < N; ++k) {
+            std::swap(cur[sz(F.swapWith[sz(k)])], cur[sz(k)]);
+            for (; op < F.fwd.size() && F.fwd[op].k == k; ++op) opOrig[op] = cur[sz(F.fwd[op].i)];
+        }
+    }
+    std::vector<int> fpos(sz(N));
+    for (int p = 0; p < N; ++p) fpos[sz(cur[sz(p)])] = p;
+
+    // ---- per-step terms: sources and history currents; TS[2 t] = +value, TS[2 t + 1] = -value
+    std::vector<int> stepSlot(sz(ap.nTerms), -1);
+    int nStep = 0;
+    struct Hist { int coefH, a, b, out; };
+    std::vector<Hist> hist;
+    std::vector<int> srcElems;
+    auto node = [&](int eq) { return (eq >= 0 && eq < N) ? eq : NP; };          // XP[NP] = 0 (ground)
+    for (int e = 0; e < ir.n_elems; ++e) {
+        const int tb = ap.termBase[sz(e)];
+        const int32_t* q = ir.eq + 4 * e;
+        if (ir.kind[e] == CSIM_V || ir.kind[e] == CSIM_I) { stepSlot[sz(tb + T_SRC_VAL)] = nStep++; srcElems.push_back(e); }
+        else if (ir.kind[e] == CSIM_C) { stepSlot[sz(tb + T_C_IH)] = nStep; hist.push_back({F.coefHandle[sz(e)], node(q[0]), node(q[1]), nStep}); ++nStep; }
+        else if (ir.kind[e] == CSIM_L) { stepSlot[sz(tb + T_L_VH)] = nStep; hist.push_back({F.coefHandle[sz(e)], node(ir.branch_eq[e]), NP, nStep}); ++nStep; }
+    }
+    const int zeroSlot = nStep, trashSlot = nStep + 1;       // padding reads the first, idle lanes write the second
+    std::vector<std::vector<int>> rhsOf(sz(NP));             // per final position: 2 * slot + negate, stamping order
+    for (int n = 0; n < gpl.nnzI(); ++n) {
+        const int p = fpos[sz(gpl.iRow[sz(n)])];
+        for (int c = gpl.iPtr[sz(n)]; c < gpl.iPtr[sz(n + 1)]; ++c) {
+            const int con = gpl.iCon[sz(c)];
+            if (stepSlot[sz(con >> 1)] < 0) {                               // a right-hand-side term this kernel does not form
+                if (std::getenv("CSIM_CG_DEBUG")) std::fprintf(stderr, "linear16: rhs term %d of row %d is not a per-step term\n", con >> 1, gpl.iRow[sz(n)]);
+                return std::string();
+            }
+            rhsOf[sz(p)].push_back(2 * stepSlot[sz(con >> 1)] + (con & 1));
+        }
+    }
+    std::vector<int> rhsMax(sz(S), 0);
+    for (int p = 0; p < NP; ++p) rhsMax[sz(p / G)] = std::max(rhsMax[sz(p / G)], static_cast<int>(rhsOf[sz(p)].size()));
+
+    // ---- the tape: every parked value goes to the lane that consumes it, in that lane's order of use
+    std::vector<int> cnt(sz(G), 0);
+    std::vector<std::vector<int>> uses(sz(F.nHandles));
+    auto take = [&](const LV& v, int lane) -> std::string {
+        const int h = handleOf(v);
+        const int r = cnt[sz(lane)]++;
+        uses[sz(h)].push_back(r * G + lane);
+        return v.neg ? "(-tp" + std::to_string(r) + ")" : "tp" + std::to_string(r);
+    };
+    // history rounds first: round r of lane g = history term r * 16 + g, its coefficient at ordinal r
+    const int histRounds = (static_cast<int>(hist.size()) + G - 1) / G;
+    std::vector<int32_t> hA(sz(std::max(1, histRounds) * G), NP), hB(sz(std::max(1, histRounds) * G), NP),
+        hOut(sz(std::max(1, histRounds) * G), trashSlot);
+    for (std::size_t n = 0; n < hist.size(); ++n) {
+        const int lane = static_cast<int>(n) % G, r = static_cast<int>(n) / G;
+        if (cnt[sz(lane)] != r || hist[n].coefH < 0) return std::string();     // cannot happen: rounds are handed out in order
+        (void)take(LV::dyn(rdHandle(hist[n].coefH)), lane);
+        hA[n] = hist[n].a; hB[n] = hist[n].b; hOut[n] = hist[n].out;
+    }
+    for (int g = 0; g < G; ++g) cnt[sz(g)] = std::max(cnt[sz(g)], histRounds);     // ordinals < histRounds belong to the rounds
+    std::vector<int> idleHist;                               // (ordinal * 16 + lane) of rounds without a term: zero-filled
+    for (int n = static_cast<int>(hist.size()); n < histRounds * G; ++n) idleHist.push_back((n / G) * G + n % G);
+
+    // ---- the substitution chain, straight-line
+    std::ostringstream ch;
+    const std::string in = "        ";
+    auto W = [&](int p) { return "w" + std::to_string(p / G); };
+    auto MK = [&](int p) { return "mk" + std::to_string(p % G); };
+    int tmp = 0, nChainInstr = 0;
+    std::vector<char> bzero(sz(NP), 0);
+    for (int p = 0; p < NP; ++p) bzero[sz(p)] = rhsOf[sz(p)].empty() ? 1 : 0;
+    ch << in << "// forward elimination replayed on the right-hand side (solver.hpp:100-113), elimination order\n";
+    {
+        int lastSrc = -1;
+        std::string srcName;
+        for (std::size_t op = 0; op < F.fwd.size(); ++op) {
+            const int k = F.fwd[op].k, P = fpos[sz(opOrig[op])];
+            const LV& f = F.fwd[op].f;
+            if (bzero[sz(k)] || f.zero()) continue;                    // b_k is a structural zero: b_P - f * 0 == b_P
+            std::string t;
+            if (f.kind == LV::DYN && cnt[sz(k % G)] < cnt[sz(P % G)]) {
+                // The multiplier may sit in the TARGET row's lane (b_k is broadcast, shared by the column's operations) or
+                // in the SOURCE row's lane (the product is formed there and broadcast): whichever lane holds fewer
+                // operands so far -- a row that receives from many columns (the ladder's border row: 256 of them) would
+                // otherwise put its whole list into one lane's registers.
+                const std::string pt = "fp" + std::to_string(tmp++);
+                t = "ft" + std::to_string(tmp++);
+                ch << in << "const double " << pt << " = " << take(f, k % G) << " * " << W(k) << ";\n"
+                   << in << "const double " << t << " = grp_bc<" << k % G << ">(" << pt << ");\n"
+                   << in << W(P) << " = fma(-" << t << ", " << MK(P) << ", " << W(P) << ");\n";
+                nChainInstr += 3;
+                bzero[sz(P)] = 0;
+                continue;
+            }
+            if (lastSrc != k) {
+                srcName = "fb" + std::to_string(k);
+                ch << in << "const double " << srcName << " = grp_bc<" << k % G << ">(" << W(k) << ");\n";
+                lastSrc = k;
+                ++nChainInstr;
+            }
+            if (f.kind == LV::CONST && std::fabs(f.c) == 1.0) t = (f.c < 0 ? "(-" + srcName + ")" : srcName);
+            else {
+                t = "ft" + std::to_string(tmp++);
+                ch << in << "const double " << t << " = " << (f.kind == LV::CONST ? lit(f.c) : take(f, P % G)) << " * " << srcName << ";\n";
+                ++nChainInstr;
+            }
+            ch << in << W(P) << " = fma(-" << t << ", " << MK(P) << ", " << W(P) << ");\n";
+            ++nChainInstr;
+            bzero[sz(P)] = 0;
+        }
+    }
+    ch << in << "// back substitution (solver.hpp:116-128): row i = N-1 .. 0, columns j ascending; x_i replaces b_i in place\n";
+    {
+        std::vector<char> xzero(sz(N), 0);
+        for (int i = N - 1; i >= 0; --i) {
+            int lastJ = -1;
+            std::string xb;
+            for (int j = i + 1; j < N; ++j) {
+                const LV& u = F.U[sz(i)][sz(j)];
+                if (u.zero() || xzero[sz(j)]) continue;
+                if (u.kind == LV::DYN && cnt[sz(j % G)] < cnt[sz(i % G)]) {       // operand in the lane of x_j: see the forward pass
+                    const std::string pt = "up" + std::to_string(tmp++), t = "ut" + std::to_string(tmp++);
+                    ch << in << "const double " << pt << " = " << take(u, j % G) << " * " << W(j) << ";\n"
+                       << in << "const double " << t << " = grp_bc<" << j % G << ">(" << pt << ");\n"
+                       << in << W(i) << " = fma(-" << t << ", " << MK(i) << ", " << W(i) << ");\n";
+                    nChainInstr += 3;
+                    bzero[sz(i)] = 0;
+                    continue;
+                }
+                if (lastJ != j) {
+                    xb = "xb" + std::to_string(tmp++);
+                    ch << in << "const double " << xb << " = grp_bc<" << j % G << ">(" << W(j) << ");\n";
+                    lastJ = j;
+                    ++nChainInstr;
+                }
+                std::string t;
+                if (u.kind == LV::CONST && std::fabs(u.c) == 1.0) t = (u.c < 0 ? "(-" + xb + ")" : xb);
+                else {
+                    t = "ut" + std::to_string(tmp++);
+                    ch << in << "const double " << t << " = " << (u.kind == LV::CONST ? lit(u.c) : take(u, i % G)) << " * " << xb << ";\n";
+                    ++nChainInstr;
+                }
+                ch << in << W(i) << " = fma(-" << t << ", " << MK(i) << ", " << W(i) << ");\n";
+                ++nChainInstr;
+                bzero[sz(i)] = 0;
+            }
+            const LV& pv = F.piv[sz(i)];
+            if (bzero[sz(i)]) { xzero[sz(i)] = 1; continue; }         // x_i = 0 / U(i,i): an exact zero, w already holds one
+            if (pv.kind == LV::CONST) {
+                if (pv.c == 1.0) continue;
+                const std::string q = "xq" + std::to_string(tmp++);
+                ch << in << "const double " << q << " = " << (pv.c == -1.0 ? "-" + W(i) : W(i) + " / " + lit(pv.c)) << ";\n"
+                   << in << W(i) << " = (g == " << i % G << ") ? " << q << " : " << W(i) << ";\n";
+                nChainInstr += 3;
+                continue;
+            }
+            const std::string pe = take(pv, i % G), re = take(F.rinv[sz(i)], i % G), q = "xq" + std::to_string(tmp++);
+            ch << in << "const double " << q << " = lin_quot(" << W(i) << ", " << pe << ", " << re << ");\n"
+               << in << W(i) << " = (g == " << i % G << ") ? " << q << " : " << W(i) << ";\n";
+            nChainInstr += 5;
+        }
+    }
+    int Tmax = 0;
+    for (int g = 0; g < G; ++g) Tmax = std::max(Tmax, cnt[sz(g)]);
+    if (Tmax == 0) Tmax = 1;
+    // registers: tape + x + w + the sixteen masks, two VGPRs each, and ~70 for addresses, descriptors and temporaries
+    if (std::getenv("CSIM_CG_DEBUG")) std::fprintf(stderr, "linear16: N=%d S=%d Tmax=%d chain instructions=%d hist rounds=%d\n", N, S, Tmax, nChainInstr, histRounds);
+    if (2 * (Tmax + 2 * S + G) + 70 > 500) return std::string();
+    std::vector<int> zeroFill = idleHist;
+    for (int g = 0; g < G; ++g)
+        for (int r = std::max(cnt[sz(g)], 0); r < Tmax; ++r) zeroFill.push_back(r * G + g);
+
+    // ---- tables
+    auto intArray = [](const std::string& name, const std::vector<int32_t>& v) {
+        std::ostringstream t;
+        t << "static __device__ const int " << name << "[" << (v.empty() ? 1 : v.size()) << "] = {";
+        if (v.empty()) t << "0";
+        for (std::size_t i = 0; i < v.size(); ++i) t << (i ? "," : "") << ((i % 32 == 31) ? "\n    " : "") << v[i];
+        t << "};\n";
+        return t.str();
+    };
+    std::vector<int32_t> srcTab(srcElems.begin(), srcElems.end());
+    const int srcRounds = (static_cast<int>(srcTab.size()) + G - 1) / G;
+    srcTab.resize(sz(std::max(1, srcRounds) * G), -1);
+    std::vector<int32_t> srcOut(srcTab.size(), trashSlot);
+    for (std::size_t i = 0; i < srcElems.size(); ++i) srcOut[i] = stepSlot[sz(ap.termBase[sz(srcElems[i])] + T_SRC_VAL)];
+    std::vector<int32_t> rhsIdx;
+    for (int s = 0; s < S; ++s)
+        for (int t = 0; t < rhsMax[sz(s)]; ++t)
+            for (int lane = 0; lane < G; ++lane) {
+                const std::vector<int>& l = rhsOf[sz(s * G + lane)];
+                rhsIdx.push_back(t < static_cast<int>(l.size()) ? l[sz(t)] : 2 * zeroSlot);
+            }
+    std::vector<int32_t> kind(ir.kind, ir.kind + ir.n_elems), slot(ir.param_slot, ir.param_slot + ir.n_elems),
+        wave(ir.wave, ir.wave + ir.n_elems), waveN(ir.wave_n, ir.wave_n + ir.n_elems);
+
+    const int oXP = 0, oTS = oXP + NP + 1, instDoubles = oTS + 2 * (nStep + 2);
+    if (instDoubles * 8 * 4 > 40 * 1024) return std::string();           // four workgroups per CU (one wave per SIMD)
+
+    std::ostringstream o;
+    o << "// ---- linear circuit, sixteen lanes per instance: tape, iterate and x_raw in registers (codegen_linear.cpp)\n"
+      << linearPrelude()
+      << intArray("l16_slot", slot) << intArray("l16_wave", wave) << intArray("l16_waveN", waveN)
+      << intArray("l16_src", srcTab) << intArray("l16_srcOut", srcOut)
+      << intArray("l16_hA", hA) << intArray("l16_hB", hB) << intArray("l16_hOut", hOut) << intArray("l16_rhs", rhsIdx)
+      << "// pivot schedule: " << (sc.str().empty() ? std::string("-") : sc.str()) << "\n"
+      << "// factorisation, once per launch, one LANE per instance; writes the tape [entry][lane of the consumer][instance]\n"
+      << "#pragma clang fp contract(off)\n"
+      << "extern \"C\" __global__ void __launch_bounds__(64)\n"
+      << "csim_lin16_factor_kernel(const double* __restrict__ params, int B, double dt, long long nSteps, int outStride,\n"
+      << "                         const int* __restrict__ done, unsigned char* __restrict__ fallback, double* __restrict__ work)\n{\n"
+      << "    const int b = blockIdx.x * 64 + threadIdx.x;\n"
+      << "    const bool inb = b < B;\n"
+      << "    const long long bb = inb ? b : B - 1;\n"
+      << "    const long long SB = B, SBW = ((long long)B + 63) / 64 * 64;     // the tape's instance stride: whole wavefronts\n"
+      << "    if (!__any(inb && done[bb] < nSteps)) return;\n"
+      << "    const bool splitFlag = outStride < 0;             // never true; opaque to the compiler\n"
+      << "    const long long vo0 = splitFlag ? 1LL : 0LL;       // always 0, opaque\n"
+      << "    double* const tapeW = work + b;                    // every lane owns a column (lanes beyond B: padding columns)\n"
+      << "    const double* const tapeF = tapeW + vo0;\n"
+      << "#define TW(n) tapeW[(long long)(n) * SBW]\n"
+      << "#define TF(n) tapeF[(long long)(n) * SBW]\n"
+      << "    bool viol = false;\n"
+      << resolveFactorText(F.text, uses)
+      << "    viol = viol || pvF != 0;\n";
+    for (int n : zeroFill) o << "    TW(" << n << ") = 0.0;\n";
+    o << "    if (inb && viol) fallback[b] = 1;     // no recorded pivot sequence fits: the general kernel runs this launch\n"
+      << "#undef TW\n#undef TF\n"
+      << "}\n\n";
+
+    o << "// time stepping: one DPP row of 16 lanes = one instance, 4 instances per wavefront\n"
+      << "extern \"C\" __global__ void __launch_bounds__(64)\n"
+      << "csim_tran_linear16_kernel(const double* __restrict__ params, int B, double dt, long long stepFirst,\n"
+      << "                          long long nSteps, const int* __restrict__ probeEq, int nProbe, int outStride,\n"
+      << "                          double* __restrict__ wave, double* __restrict__ xio, long long* __restrict__ iters,\n"
+      << "                          unsigned* __restrict__ status, int* __restrict__ stepIters,\n"
+      << "                          unsigned char* __restrict__ fallback, int* __restrict__ done,\n"
+      << "                          int* __restrict__ violFlag, const double* __restrict__ work)\n{\n"
+      << "    __shared__ double lds[4 * " << instDoubles << "];\n"
+      << "    const int lane = threadIdx.x, g = lane & 15, q = lane >> 4;\n"
+      << "    const int b = blockIdx.x * 4 + q;\n"
+      << "    const bool inb = b < B;\n"
+      << "    const long long bb = inb ? b : B - 1;      // out-of-range groups shadow the last instance, never store\n"
+      << "    const long long SB = B, SBW = ((long long)B + 63) / 64 * 64;\n"
+      << "    if (!__any(inb && done[bb] < nSteps)) return;\n"
+      << "    double* const XP = lds + q * " << instDoubles << " + " << oXP << ";   // state at the start of the step (history, checkpoint, probes); XP[" << NP << "] = 0\n"
+      << "    double* const TS = lds + q * " << instDoubles << " + " << oTS << ";   // per-step terms with sign: TS[2t] = +v, TS[2t+1] = -v; slot " << zeroSlot << " = 0\n"
+      << "    auto P = [&](int slot) -> double { return params[(long long)slot * SB + bb]; };\n";
+    for (int t = 0; t < G; ++t) o << "    const double mk" << t << " = (g == " << t << ") ? 1.0 : 0.0;\n";
+    o << "    // the tape: this lane's operands in its order of use\n";
+    for (int r = 0; r < Tmax; ++r) o << "    const double tp" << r << " = work[(long long)(" << r * G << " + g) * SBW + bb];\n";
+    for (int r = 0; r < srcRounds; ++r)
+        o << "    const int se" << r << " = l16_src[" << r * G << " + g];       // source evaluated by this lane in round " << r << " (-1: none)\n"
+          << "    const int sq" << r << " = se" << r << " >= 0 ? se" << r << " : 0;\n"
+          << "    const int ssl" << r << " = l16_slot[sq" << r << "], sto" << r << " = l16_srcOut[" << r * G << " + g], swv" << r << " = l16_wave[sq" << r
+          << "], swn" << r << " = l16_waveN[sq" << r << "];\n";
+    for (int r = 0; r < histRounds; ++r)
+        o << "    const int ha" << r << " = l16_hA[" << r * G << " + g], hb" << r << " = l16_hB[" << r * G << " + g], ho" << r << " = l16_hOut[" << r * G << " + g];\n";
+    {
+        int base = 0;
+        for (int s = 0; s < S; ++s)
+            for (int t = 0; t < rhsMax[sz(s)]; ++t, ++base) o << "    const int ri" << s << "_" << t << " = l16_rhs[" << base * G << " + g];\n";
+    }
+    o << "    for (int i = g; i < " << 2 * (nStep + 2) << "; i += 16) TS[i] = 0.0;\n"
+      << "    if (g == 0) XP[" << NP << "] = 0.0;\n";
+    for (int s = 0; s < S; ++s)
+        o << "    double x" << s << " = (" << s * G << " + g < " << N << ") ? xio[(long long)(" << s * G << " + g) * SB + bb] : 0.0;\n"
+          << "    XP[" << s * G << " + g] = x" << s << ";\n";
+    o << "    __syncthreads();\n"
+      << "    unsigned st = inb ? status[bb] : 0u;\n"
+      << "    bool viol = inb && fallback[bb] != 0;      // the factor kernel found no recorded pivot sequence to fit\n"
+      << "    bool dead = !inb || (st & ST_TRAN_NONFINITE) != 0u;   // the reference would have thrown: stay stopped\n"
+      << "    long long itTotal = 0;\n"
+      << "    long long sdone = (inb && !dead) ? (long long)done[bb] : nSteps;\n"
+      << "    if (stepFirst == 0 && sdone == 0 && wave && inb)\n"
+      << "        for (int pq = g; pq < nProbe; pq += 16) wave[((long long)pq) * SB + b] = XP[probeEq[pq]];\n"
+      << "    int smin = (int)(sdone < nSteps ? sdone + 1 : nSteps + 1);\n"
+      << "    for (int m = 32; m >= 1; m >>= 1) { const int ot = __shfl_xor(smin, m); smin = ot < smin ? ot : smin; }\n"
+      << "    smin = __builtin_amdgcn_readfirstlane(smin);\n"
+      << "    int ophase = (int)((stepFirst + smin) % outStride);\n"
+      << "    long long orow = (stepFirst + smin) / outStride;\n"
+      << "    for (long long s = smin; s <= nSteps; ++s, ++ophase) {\n"
+      << "        if (ophase == outStride) { ophase = 0; ++orow; }\n"
+      << "        if (!__any(!dead && !viol && sdone < nSteps)) break;\n"
+      << "        const bool live = !dead && !viol && sdone + 1 == s;\n"
+      << "        const long long gstep = stepFirst + s;\n"
+      << "        const double tNow = (double)(int)gstep * dt;\n"
+      << "        // per-step terms: history currents -Gc * vPrev, -Req * iPrev (tanalisis.cpp:77,308) and sources (sim.hpp:160-162);\n"
+      << "        // all LDS reads of a phase before its first write\n";
+    for (int r = 0; r < histRounds; ++r)
+        o << "        const double hp" << r << " = XP[ha" << r << "], hq" << r << " = XP[hb" << r << "];\n";
+    for (int r = 0; r < srcRounds; ++r)
+        o << "        {\n"
+          << "            const double v = se" << r << " >= 0 ? grp_source_tran([&](int i) { return P(ssl" << r << " + i); }, swv" << r << ", swn" << r << ", tNow, " << lit(K.pi) << ") : 0.0;\n"
+          << "            TS[2 * sto" << r << "] = v; TS[2 * sto" << r << " + 1] = -v;\n"
+          << "        }\n";
+    for (int r = 0; r < histRounds; ++r)
+        o << "        {\n"
+          << "            const double v = -tp" << r << " * (hp" << r << " - hq" << r << ");\n"
+          << "            TS[2 * ho" << r << "] = v; TS[2 * ho" << r << " + 1] = -v;\n"
+          << "        }\n";
+    o << "        // right-hand side at the rows' final pivot positions, per-step terms summed in the reference's stamping order\n";
+    for (int s = 0; s < S; ++s)
+        for (int t = 0; t < rhsMax[sz(s)]; ++t) o << "        const double rt" << s << "_" << t << " = TS[ri" << s << "_" << t << "];\n";
+    for (int s = 0; s < S; ++s) {
+        o << "        double w" << s << " = 0.0;\n";
+        for (int t = 0; t < rhsMax[sz(s)]; ++t) o << "        w" << s << " += rt" << s << "_" << t << ";\n";
+    }
+    o << ch.str()
+      << "        // Newton passes: x_raw is the same in every pass of the step; damped update, norm, convergence\n"
+      << "        // (tanalisis.cpp:365-376) are executed pass by pass.  A group that is done keeps its iterate through a\n"
+      << "        // zero step length (x + 0 * (x_raw - x) == x), not a branch.\n"
+      << "        bool active = live;\n"
+      << "        int it = 0;\n"
+      << "        for (int iter = 0; iter < " << K.tran_max_iters << "; ++iter) {\n"
+      << "            if (!__any(active)) break;\n"
+      << "            const double al = active ? " << lit(K.tran_alpha) << " : 0.0;\n"
+      << "            double ss = 0.0;\n";
+    for (int s = 0; s < S; ++s)
+        o << "            { const double xn = x" << s << " + al * (w" << s << " - x" << s << "); const double d = xn - x" << s << "; ss += d * d; x" << s << " = xn; }\n";
+    o << "            ss = grp_sum16(ss);\n"
+      << "            const double err = sqrt(ss);\n"
+      << "            const bool good = active && (ss < 1.0e300);      // else: a non-finite solve, the general kernel classifies it\n"
+      << "            const bool conv = err < " << lit(K.tran_tol) << ";\n"
+      << "            viol = viol || (active && !good);\n"
+      << "            it += good ? 1 : 0;\n"
+      << "            if (good && !conv && iter == " << (K.tran_max_iters - 1) << ") st |= ST_TRAN_NONCONV;   // tanalisis.cpp:372-376 (kept, as upstream)\n"
+      << "            active = good && !conv;\n"
+      << "        }\n"
+      << "        if (live && !viol) {\n";
+    for (int s = 0; s < S; ++s) o << "            XP[" << s * G << " + g] = x" << s << ";\n";
+    o << "            itTotal += it;\n"
+      << "            if (stepIters && g == 0) stepIters[(s - 1) * SB + b] = it;\n"
+      << "            if (wave && ophase == 0) {\n"
+      << "                const long long row = orow;\n"
+      << "                for (int pq = g; pq < nProbe; pq += 16) wave[(row * nProbe + pq) * SB + b] = XP[probeEq[pq]];\n"
+      << "            }\n"
+      << "            sdone = s;\n"
+      << "        }\n"
+      << "    }\n\n"
+      << "    if (inb) {\n"
+      << "        // XP: the state after the last completed step -- for a violated instance the start of the failing step\n";
+    for (int s = 0; s < S; ++s)
+        o << "        if (" << s * G << " + g < " << N << ") xio[(long long)(" << s * G << " + g) * SB + b] = XP[" << s * G << " + g];\n";
+    o << "        if (g == 0) {\n"
+      << "            if (viol) fallback[b] = 1;\n"
+      << "            iters[b] += itTotal;\n"
+      << "            status[b] |= st;\n"
+      << "            done[b] = (int)sdone;\n"
+      << "            if (sdone < nSteps) violFlag[0] = 1;\n"
+      << "        }\n"
+      << "    }\n"
+      << "}\n#pragma clang fp contract(fast)\n\n";
+    (void)nChainInstr;
+    if (workDoubles) *workDoubles = Tmax * G;
     return o.str();
 }
 

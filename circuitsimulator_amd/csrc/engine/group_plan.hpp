@@ -113,6 +113,10 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
 void interpretGroupPlan(const GroupPlan& gp, const AssemblyPlan& ap, const csim_ir& ir, const double* T, double eps,
                         double* x, bool* violated, bool* planError = nullptr);
 
+// device code shared by the sixteen-lanes-per-instance kernels (DPP broadcast / row sum, source waveforms, the
+// MOSFET linearisation): emitted once per generated library, before emitGroupKernel's / emitLinearGroupKernel's text
+std::string groupPreludeSource(const csim_ir& ir);
+
 // the __global__ kernel "csim_tran_group_kernel" + its tables; "" if the circuit does not fit.  One solve
 // body per schedule, tried in order per Newton pass for the groups whose checks failed so far.
 std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std::vector<PivotSchedule>& schedules,

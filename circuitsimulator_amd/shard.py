@@ -43,7 +43,14 @@ def init_process_group(backend=None):
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29500")
+    if "MASTER_PORT" not in os.environ:
+        if world > 1:
+            raise RuntimeError("WORLD_SIZE > 1 needs MASTER_PORT in the environment (the launcher sets it)")
+        import socket                         # a forced single-rank group: any free port will do
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        s.close()
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
     kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
@@ -120,6 +127,25 @@ def all_reduce_sum(value, device=None):
     t = torch.tensor([value], dtype=torch.float64, device=_dev(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.item()
+
+
+def all_reduce_sum_int(value, device=None):
+    """Sum of a python int over all ranks as int64 (NR-iteration and status counters, SURVEY.md 8e #4)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=_dev(device))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def backend_name():
+    """"nccl" (= RCCL), "gloo", or "none" when this run has no process group."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_backend()
+    return "none"
 
 
 def all_reduce_max(value, device=None):

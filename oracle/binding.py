@@ -43,6 +43,8 @@ def lib():
         L.oracle_dc_gs.argtypes = [vp, vp, i64, vp, vp, vp]
         L.oracle_tran.restype = i64
         L.oracle_tran.argtypes = [vp, vp, i64, dbl, dbl, dbl, vp, vp, i64, vp, vp, vp, vp, vp]
+        L.oracle_tran_batch_mt.restype = C.c_int
+        L.oracle_tran_batch_mt.argtypes = [vp, vp, i64, C.c_int, C.c_int, dbl, dbl, C.c_int, vp]
         L.oracle_tran_num_steps.restype = i64
         L.oracle_tran_num_steps.argtypes = [dbl, dbl]
         L.oracle_write_csv_rows.restype = C.c_int
@@ -159,6 +161,18 @@ def tran(ir, N, params, b, tstep, tstop, tstart=0.0, x0=None, want_rows=True, wa
         raise RuntimeError("oracle_tran failed: %d" % rc)
     return dict(rows=rows[:nrows.value] if rows is not None else None, x_final=xf, iters=its.value,
                 status=st.value, n_steps=rc, step_iters=si[:ns] if si is not None else None)
+
+
+def tran_batch_mt(ir, params, b_first, n_inst, tstep, tstop, n_threads):
+    """n_inst instances of a slot-major [P][B] table on n_threads host threads -> (iters [n_inst], threads run)"""
+    table = np.ascontiguousarray(params, dtype=np.float64)
+    assert table.ndim == 2 and b_first + n_inst <= table.shape[1]
+    its = np.zeros(max(n_inst, 1), dtype=np.int64)
+    ran = lib().oracle_tran_batch_mt(ir, table.ctypes.data, table.shape[1], b_first, n_inst, tstep, tstop, n_threads,
+                                     its.ctypes.data)
+    if ran < 0:
+        raise RuntimeError("oracle_tran_batch_mt failed")
+    return its[:n_inst], ran
 
 
 def pivot_log(enable=True):

@@ -14,6 +14,7 @@
 #include "mna_oracle.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -748,4 +749,45 @@ int oracle_write_csv_rows(const char* path, const char* header, const double* ro
     }
     fclose(f);
     return 0;
+}
+
+/* ------------------------------------------------------------------ *
+ * Host-threaded driver for the CPU baseline of bench.py ("OpenMP over instances on all
+ * cores"): n_inst instances of a slot-major table run oracle_tran() concurrently on n_threads POSIX threads,
+ * instances handed out one at a time from a shared counter.  Not part of the restatement proper.
+ * ------------------------------------------------------------------ */
+typedef struct {
+    const csim_ir* ir; const double* params; int64_t pstride; int b_first, n_inst;
+    double tstep, tstop; int64_t* iters_out; int next; pthread_mutex_t lock;
+} batch_job;
+
+static void* batch_worker(void* arg)
+{
+    batch_job* j = (batch_job*)arg;
+    for (;;) {
+        pthread_mutex_lock(&j->lock);
+        const int i = j->next < j->n_inst ? j->next++ : -1;
+        pthread_mutex_unlock(&j->lock);
+        if (i < 0) return NULL;
+        int64_t it = 0;
+        uint32_t st = 0;
+        oracle_tran(j->ir, j->params + (j->b_first + i), j->pstride, j->tstep, j->tstop, 0.0, NULL, NULL, 0, NULL, NULL,
+                    &it, NULL, &st);
+        j->iters_out[i] = it;
+    }
+}
+
+int oracle_tran_batch_mt(const csim_ir* ir, const double* params, int64_t pstride, int b_first, int n_inst,
+                         double tstep, double tstop, int n_threads, int64_t* iters_out)
+{
+    if (!ir || !params || !iters_out || n_inst < 0 || n_threads < 1) return -1;
+    batch_job j = {ir, params, pstride, b_first, n_inst, tstep, tstop, iters_out, 0, PTHREAD_MUTEX_INITIALIZER};
+    if (n_threads > 1024) n_threads = 1024;
+    pthread_t th[1024];
+    int started = 0;
+    for (int t = 0; t < n_threads; ++t)
+        if (pthread_create(&th[started], NULL, batch_worker, &j) == 0) ++started;
+    if (started == 0) batch_worker(&j);
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    return started;
 }

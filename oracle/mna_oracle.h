@@ -84,6 +84,12 @@ int64_t oracle_tran(const csim_ir* ir, const double* params, int64_t pstride,
                     double* x_final, int64_t* iters, int32_t* iters_per_step,
                     uint32_t* status);
 
+/* bench.py's all-cores CPU baseline: instances b_first .. b_first+n_inst-1 of a slot-major table, each through
+ * oracle_tran() from its own DC point, on n_threads POSIX threads.  iters_out[n_inst].  Returns the number of
+ * threads that ran, or -1. */
+int oracle_tran_batch_mt(const csim_ir* ir, const double* params, int64_t pstride, int b_first, int n_inst,
+                         double tstep, double tstop, int n_threads, int64_t* iters_out);
+
 /* floor(tstop/dt + 1e-12), src/tanalisis.cpp:238 */
 int64_t oracle_tran_num_steps(double tstep, double tstop);
 

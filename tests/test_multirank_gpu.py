@@ -77,3 +77,40 @@ def test_two_ranks_share_the_gpu_and_equal_one_rank(tmp_path):
     assert np.array_equal(a["gathered"], b["gathered"])            # bitwise: same kernel, same per-instance data
     assert float(a["total_iters"]) == float(b["total_iters"])     # all-reduced NR count == one-rank count
     assert rec1["n_gpus"] == 1
+
+
+def test_bare_gpus_2_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher environment (how a driver may start it): the process starts two
+    fresh child ranks itself, relays rank 0's single JSON line and exits 0."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(CSIM_SHARE_GPU="1", CSIM_DIST_BACKEND="gloo")
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "128", "--steps", "2",
+                          "--warmup", "1", "--tsteps", "30", "--no-cpu", "--large-batch", "0"], env=env, cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    out, err = _finish(p)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["gathered_shape"][1] == 256 and rec["dist_backend"] == "gloo"
+    assert rec["config"]["flagged_instances"] == 0
+
+
+def test_collectives_run_through_rccl():
+    """One rank with a forced process group on the nccl backend (= RCCL on ROCm): the netlist broadcast, the
+    all-gather of the probe voltages and the int64 all-reduce of the counters go through RCCL on this box."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(CSIM_FORCE_DIST="1", CSIM_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "256", "--steps", "2",
+                          "--warmup", "1", "--tsteps", "30", "--no-cpu", "--large-batch", "0"], env=env, cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    out, err = _finish(p)
+    rec = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+    assert rec["dist_backend"] == "nccl" and rec["n_gpus"] == 1
+    assert rec["gathered_shape"][1] == 256 and rec["value"] > 0
+    assert isinstance(rec["config"]["flagged_instances"], int) and rec["config"]["flagged_instances"] == 0

@@ -72,3 +72,21 @@ def test_two_ranks_equal_single_rank(tmp_path, total):
         got = np.load(os.path.join(str(tmp_path), "r%d.npy" % r))
         assert got.shape == (2, total)
         assert np.array_equal(got, whole)          # G-way result == 1-way result, bitwise
+
+
+def test_bare_multi_gpu_bench_is_its_own_launcher():
+    """`python bench.py --gpus 2` without a launcher environment must not exit 2 ("use torch.distributed.run"):
+    it starts one child per rank itself.  On a box without a GPU the children stop with "no GPU visible"
+    (status 3) and the parent reports which ranks failed; it never imports torch or touches a device itself."""
+    import subprocess
+    import sys
+    from conftest import ROOT, has_gpu
+    if has_gpu():
+        pytest.skip("covered by tests/test_multirank_gpu.py on a GPU box")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 1, (p.returncode, p.stderr[-500:])
+    # (the first rank to fail stops the run: the other one is reported with 3 too, or as killed)
+    assert "ranks failed" in p.stderr and "no GPU visible" in p.stderr and ", 3)" in p.stderr
+    assert p.stdout.strip() == ""
