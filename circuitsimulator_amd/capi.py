@@ -68,6 +68,7 @@ PROTOTYPES = {
                                       _vp, _vp, _vp, _vp, _vp, _vp]),
     "csim_dc_batch": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "csim_tran_batch": (C.c_int, [_vp, _vp, _i32, _dbl, _dbl, _dbl, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "csim_tran_write_csv": (C.c_int, [_vp, _vp, _i32, _i32, _dbl, _dbl, _dbl, _vp, _i32, _cp]),
     "csim_tran_num_rows": (_i64, [_dbl, _dbl, _dbl, _i32]),
     "csim_tran_num_steps": (_i64, [_dbl, _dbl]),
     "csim_lu_solve_batch": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp]),

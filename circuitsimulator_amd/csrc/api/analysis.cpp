@@ -87,6 +87,26 @@ BatchTranResult BatchEngine::tran(const std::vector<double>& params, int B, doub
     return r;
 }
 
+void BatchEngine::writeCsv(const std::vector<double>& params, int B, int instance, const SimulationConfig& sim,
+                           const std::string& path, const std::vector<int32_t>& probeEq)
+{
+    std::vector<int32_t> cols = probeEq;
+    if (cols.empty()) {
+        // node-voltage probes of .PLOTNV / .PRINT cards, in card order (src/parser.cpp:630-723)
+        for (const PrintCommand& pc : sim.printCommands)
+            for (const ProbeSpec& ps : pc.probes) {
+                if (ps.kind != ProbeKind::NodeVoltage) continue;
+                const int eq = csim_netlist_node_eq(nl_, ps.node1.c_str());
+                if (eq >= 0 && std::find(cols.begin(), cols.end(), eq) == cols.end()) cols.push_back(eq);
+            }
+    }
+    if (cols.empty())
+        for (int i = 0; i < numUnknowns(); ++i) cols.push_back(i);
+    if (csim_tran_write_csv(eng_, params.empty() ? nullptr : params.data(), B, instance, sim.tran.tstep, sim.tran.tstop,
+                            sim.tran.tstart, cols.data(), static_cast<int32_t>(cols.size()), path.c_str()) != CSIM_OK)
+        fail("csim_tran_write_csv");
+}
+
 } // namespace csim
 
 // ------------------------------------------------------------ dcanalysis.hpp

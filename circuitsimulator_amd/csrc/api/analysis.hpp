@@ -55,6 +55,12 @@ public:
     BatchTranResult tran(const std::vector<double>& params, int B, double tstep, double tstop, double tstart,
                          const std::vector<int32_t>& probeEq, int outStride);
 
+    // the transient of instance `instance` of params ([B][P], empty = nominal) as the reference's CSV
+    // (src/tanalisis.cpp:189-231); probeEq empty: the netlist's .PLOTNV/.PRINT probes when `sim` names any, else
+    // every unknown.  Throws std::runtime_error on failure.
+    void writeCsv(const std::vector<double>& params, int B, int instance, const SimulationConfig& sim,
+                  const std::string& path, const std::vector<int32_t>& probeEq = {});
+
 private:
     CircuitIR ir_;
     csim_netlist* nl_ = nullptr;      // netlist handle wrapping ir_ for the C-ABI

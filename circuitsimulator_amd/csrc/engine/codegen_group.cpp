@@ -196,7 +196,12 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     // LDS carve-up per instance (doubles)
     const int nT1 = ap.nTerms + 1;                              // + one dummy term (always 0) for padded table entries
     const int oXS = 0, oXP = oXS + NP + 1, oTT = oXP + NP + 1, oTS = oTT + nT1, oPL = oTS + 2 * nT1, oST = oPL + ir.n_params;
-    const int instDoubles = oST + (nStage + 1) * G;
+    // Per-instance stride: the four groups of a wave read the same [row][16] cells of their own instance in one
+    // ds_read_b64, 32 lanes (two groups) per pass over the 64 four-byte banks: a stride of 16 doubles (mod 32)
+    // puts the second group of a pass on the other half of the banks (an odd stride, 847 on dbmixer, overlapped them:
+    // SQ_LDS_BANK_CONFLICT was 31 % of the LDS-active cycles, profiles/r02_group16_b4096_summary.md)
+    int instDoubles = oST + (nStage + 1) * G;
+    while (instDoubles % 32 != 16) ++instDoubles;
     if (instDoubles * 8 * 4 > 64 * 1024) return std::string();  // keep 2+ waves per CU possible; larger circuits: no group kernel
 
     std::ostringstream o;      // (the shared device code, groupPreludeSource(), is emitted by the caller)
@@ -444,7 +449,8 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     const std::string in = "            ";
     o << "        bool active = live;\n"
       << "        int it = 0;\n"
-      << (guard ? "        double nearMin = 1.0;   // smallest |err - tol| of this step's passes\n" : "");
+      << (guard ? (gopt.nearForm == 0 ? "        double nearMin = 1.0;   // smallest |err - tol| of this step's passes\n"
+                                      : "        bool nearAny = false;   // some pass of this step had err within the band around tol\n") : "");
     o << "        for (int iter = 0; iter < " << K.tran_max_iters << "; ++iter) {\n"
       << "            if (!__any(active)) break;\n";
     if (!piped) emitMos(in);
@@ -672,7 +678,9 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
         // near-threshold guard: how close did `err < tol` (tanalisis.cpp:369) come to a tie in this step?  Two
         // instructions per pass; everything else happens once per step, below.  (Passes after a group has converged
         // are included: they can only raise a false alarm, which costs a verification and changes nothing.)
-        o << in << "nearMin = fmin(nearMin, fabs(err - " << lit(K.tran_tol) << "));\n";
+        o << in << (gopt.nearForm == 0
+                    ? "nearMin = fmin(nearMin, fabs(err - " + lit(K.tran_tol) + "));\n"
+                    : "nearAny = nearAny || (err > " + lit(K.tran_tol * (1.0 - gopt.nearBand)) + " && err < " + lit(K.tran_tol * (1.0 + gopt.nearBand)) + ");\n");
     o << in << "viol = viol || (active && !good) || (good && slow);\n"
       << in << "it += good ? 1 : 0;\n";
     for (int s = 0; s < S; ++s) o << in << "xo" << s << " = good ? xn" << s << " : xo" << s << ";\n";
@@ -697,7 +705,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
         // `err < tol` decided within the rounding noise of this kernel's arithmetic: the group goes on speculatively, the
         // step's start state is kept, and the engine has the faithful kernel verify the step's pass count afterwards.
         // One checkpoint per launch: a second such step stops the group at the start of that step.
-        o << "        const bool nearEvent = live && !viol && nearMin <= " << lit(gopt.nearBand * K.tran_tol) << ";\n"
+        o << "        const bool nearEvent = live && !viol && " << (gopt.nearForm == 0 ? "nearMin <= " + lit(gopt.nearBand * K.tran_tol) : std::string("nearAny")) << ";\n"
           << "        viol = viol || (nearEvent && nearS != 0);\n";
     o << "        if (live && !viol) {\n";
     if (guard) {

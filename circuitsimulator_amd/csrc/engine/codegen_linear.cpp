@@ -978,7 +978,9 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
     std::vector<int32_t> kind(ir.kind, ir.kind + ir.n_elems), slot(ir.param_slot, ir.param_slot + ir.n_elems),
         wave(ir.wave, ir.wave + ir.n_elems), waveN(ir.wave_n, ir.wave_n + ir.n_elems);
 
-    const int oXP = 0, oTS = oXP + NP + 1, instDoubles = oTS + 2 * (nStep + 2);
+    const int oXP = 0, oTS = oXP + NP + 1;
+    int instDoubles = oTS + 2 * (nStep + 2);
+    while (instDoubles % 32 != 16) ++instDoubles;       // bank halves for the two groups of a 32-lane LDS pass (codegen_group.cpp)
     if (instDoubles * 8 * 4 > 40 * 1024) return std::string();           // four workgroups per CU (one wave per SIMD)
 
     std::ostringstream o;

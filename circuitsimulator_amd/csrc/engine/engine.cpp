@@ -247,6 +247,7 @@ int csim_engine_create(const csim_netlist* nl, int32_t device, csim_engine** out
     eng->cfg = configFromEnvironment();
     eng->cir = nl->cir;
     eng->cir.view();
+    eng->netlistProbes = nl->probeEq;
     eng->plan = csim::buildAssemblyPlan(*eng->cir.view());
     eng->big = ir->n_unknowns > 63;
 
@@ -826,6 +827,51 @@ int csim_tran_batch(csim_engine* eng, const double* params, int32_t B, double ts
     if (x_final)  HIPCHK(hipMemcpy(x_final, dXt.p, sizeof(double) * (size_t)N * B, hipMemcpyDeviceToHost));
     if (nr_iters) HIPCHK(hipMemcpy(nr_iters, dIt.p, sizeof(int64_t) * (size_t)B, hipMemcpyDeviceToHost));
     if (status)   HIPCHK(hipMemcpy(status, dSt.p, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost));
+    return CSIM_OK;
+}
+
+// one instance of a batch description as the reference's CSV (src/tanalisis.cpp:189-231)
+int csim_tran_write_csv(csim_engine* eng, const double* params, int32_t B, int32_t instance, double tstep, double tstop,
+                        double tstart, const int32_t* probe_eq, int32_t n_probe, const char* path)
+{
+    if (!eng || !path || B <= 0 || instance < 0 || instance >= B || n_probe < 0 || (n_probe > 0 && !probe_eq)) {
+        setError("csim_tran_write_csv: bad argument");
+        return CSIM_ERR_ARG;
+    }
+    const csim_ir* ir = eng->cir.view();
+    const int N = ir->n_unknowns, P = ir->n_params;
+    std::vector<int32_t> cols;
+    if (n_probe > 0) cols.assign(probe_eq, probe_eq + n_probe);
+    else if (!eng->netlistProbes.empty()) cols.assign(eng->netlistProbes.begin(), eng->netlistProbes.end());
+    else for (int i = 0; i < N; ++i) cols.push_back(i);
+    for (int32_t c : cols)
+        if (c < 0 || c >= N) { setError("csim_tran_write_csv: probe equation index out of range"); return CSIM_ERR_ARG; }
+    const int64_t rows = csim_tran_num_rows(tstep, tstop, tstart, 1);
+    if (rows < 0) { setError("Invalid .TRAN card: tstep and tstop must be > 0"); return CSIM_ERR_CONFIG; }
+    const int np = static_cast<int>(cols.size());
+    std::vector<double> wave(static_cast<std::size_t>(rows) * static_cast<std::size_t>(np), 0.0), xf(static_cast<std::size_t>(N), 0.0);
+    int64_t iters = 0;
+    uint32_t status = 0;
+    const int rc = csim_tran_batch(eng, params ? params + static_cast<std::size_t>(instance) * static_cast<std::size_t>(P) : nullptr, 1,
+                                   tstep, tstop, tstart, cols.data(), np, 1, wave.data(), xf.data(), &iters, &status);
+    if (rc != CSIM_OK) return rc;
+    if (status & CSIM_ST_TRAN_NONFINITE) { setError("Transient: LU produced NaN/Inf."); return CSIM_ERR_UNSUPPORTED; }   // tanalisis.cpp:361 throws
+    FILE* f = std::fopen(path, "w");
+    if (!f) { setError(std::string("Cannot open transient output file '") + path + "'."); return CSIM_ERR_IO; }
+    std::fputs("time", f);
+    for (int32_t c : cols)
+        std::fprintf(f, ",%s(%s)", c < ir->n_node_eq ? "V" : "I", eng->cir.eqNames[static_cast<std::size_t>(c)].c_str());
+    std::fputc('\n', f);
+    const int64_t nSteps = csim_tran_num_steps(tstep, tstop);
+    const int64_t first = nSteps + 1 - rows;                 // rows with t < tstart are suppressed (tanalisis.cpp:208-209)
+    for (int64_t k = 0; k < rows; ++k) {
+        const int64_t row = first + k;
+        const double t = row == 0 ? 0.0 : static_cast<double>(static_cast<int>(row)) * tstep;
+        std::fprintf(f, "%.9e", t);
+        for (int i = 0; i < np; ++i) std::fprintf(f, ",%.9e", wave[static_cast<std::size_t>(k) * static_cast<std::size_t>(np) + static_cast<std::size_t>(i)]);
+        std::fputc('\n', f);
+    }
+    if (std::fclose(f) != 0) { setError(std::string("write error on '") + path + "'"); return CSIM_ERR_IO; }
     return CSIM_OK;
 }
 

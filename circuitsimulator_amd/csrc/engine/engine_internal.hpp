@@ -98,6 +98,8 @@ struct csim_engine {
     // Gauss-Seidel DC: off-diagonal structure of the DC system per row (uploaded on first use)
     const int32_t *dGsRowPtr = nullptr, *dGsRowCol = nullptr;
 
+    std::vector<int> netlistProbes;        // .PLOTNV / .PRINT node-voltage probes of the netlist (default CSV columns)
+
     // probe list of the most recent transient call
     int32_t* dProbe = nullptr;
     std::vector<int32_t> probeCache;

@@ -267,6 +267,25 @@ class Engine:
             st.ctypes.data))
         return wave, xf, it, st
 
+    def write_csv(self, path, params=None, instance=0, tstep=None, tstop=None, tstart=None, probes=None):
+        """csim_tran_write_csv: the transient of one instance of params ([B][P] numpy, instance-major; None = nominal)
+        as the reference's CSV.  probes None: the netlist's .PLOTNV/.PRINT probes if any, else every unknown."""
+        nl = self.netlist
+        tstep = nl.tstep if tstep is None else tstep
+        tstop = nl.tstop if tstop is None else tstop
+        tstart = nl.tstart if tstart is None else tstart
+        B = 1
+        if params is not None:
+            params = np.ascontiguousarray(params, dtype=np.float64)
+            B = params.shape[0]
+        pe, n_probe = None, 0
+        if probes:
+            n_probe = len(probes)
+            pe = (C.c_int32 * n_probe)(*probes)
+        capi.check(capi.lib().csim_tran_write_csv(
+            self._h, params.ctypes.data if params is not None else None, B, int(instance), tstep, tstop, tstart,
+            pe, n_probe, str(path).encode()))
+
     def jit_scheduled(self, params, tstep=None, plan_steps=200):
         """Plan + generate + hipcc + load the lane-per-instance kernel for this netlist (needs hipcc)."""
         tstep = self.netlist.tstep if tstep is None else tstep

@@ -209,6 +209,18 @@ int  csim_tran_batch(csim_engine* eng, const double* params, int32_t B,
                      double tstep, double tstop, double tstart,
                      const int32_t* probe_eq, int32_t n_probe, int32_t out_stride,
                      double* wave_out, double* x_final, int64_t* nr_iters, uint32_t* status);
+/* The transient of ONE instance of a batch description, written as the reference's CSV
+ * (src/tanalisis.cpp:189-231: header "time,V(<node>)...,I(<source or inductor>)...", values "%.9e", one row per
+ * time step, rows with t < tstart suppressed) -- what plot_tran.py reads.  For the Monte-Carlo instances one
+ * wants to look at; the whole batch's waveforms go through csim_tran_batch's wave_out.
+ *   params    [B][P] instance-major host table or NULL (nominal); `instance` picks its row
+ *   probe_eq  columns (equation indices) in file order; n_probe == 0: the netlist's .PLOTNV / .PRINT probes
+ *             when it names any (src/parser.cpp:630-723), else every unknown -- the reference's own file
+ * Runs the DC operating point and the transient of that instance alone (a batch of one on the engine's
+ * kernels) and formats on the host.  CSIM_ERR_IO if the file cannot be written.                       */
+int  csim_tran_write_csv(csim_engine* eng, const double* params, int32_t B, int32_t instance,
+                         double tstep, double tstop, double tstart,
+                         const int32_t* probe_eq, int32_t n_probe, const char* path);
 /* number of rows csim_tran_batch writes per instance for these numbers       */
 int64_t csim_tran_num_rows(double tstep, double tstop, double tstart, int32_t out_stride);
 int64_t csim_tran_num_steps(double tstep, double tstop);

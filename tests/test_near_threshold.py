@@ -93,9 +93,10 @@ def test_faithful_dc_kernel_is_bitwise_the_general_kernel(torch_mod, dbmixer_nl)
 
 @pytest.mark.parametrize("lanes", [16, 1])
 def test_near_threshold_decisions_are_verified_and_rolled_back(torch_mod, dbmixer_nl, tmp_path, monkeypatch, lanes):
-    """dbmixer.sp kernels generated with a guard band of 2 % (the shipped band is 2e-8: its events are too rare
-    to test), so that near-threshold events, second events within a launch, verification and -- with the test
-    aid near_test_rollback -- roll-backs all happen many times in 60 steps.  Whatever the path, per-step NR
+    """dbmixer.sp kernels generated with a guard band of 15 % (the shipped band is 2e-8: its events are too rare to
+    test -- and, the Monte-Carlo instances' trajectories being near copies of each other, so were those of a 2 %
+    band in 60 steps), so that near-threshold events, second events within a launch, verification and -- with the
+    test aid near_test_rollback -- roll-backs all happen many times.  Whatever the path, per-step NR
     counts and status equal the general kernel's, states agree within the bar, and the synchronous and the
     asynchronous form of the call give the same bits."""
     from circuitsimulator_amd import Engine
@@ -109,7 +110,7 @@ def test_near_threshold_decisions_are_verified_and_rolled_back(torch_mod, dbmixe
     ref = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True, chunks=[25, 35], probes=nl.probes)
     eng.set_kernel("auto")
     sched, dc_sched = eng.loaded_schedules()
-    eng.set_option("jit_gen_opts", "near_band=0.02")
+    eng.set_option("jit_gen_opts", "near_band=0.15")
     eng.jit_with_schedules(sched, dc_sched)
     eng.set_option("lanes_per_instance", lanes)
     assert eng.lanes_for_batch(B) == lanes
@@ -128,7 +129,7 @@ def test_near_threshold_decisions_are_verified_and_rolled_back(torch_mod, dbmixe
         dv, dr = eng.stat("near_verified") - v0, eng.stat("near_rolled_back") - r0
         print("%s lanes=%d: %d decisions verified, %d rolled back" % (mode, lanes, dv, dr))
         if mode == "sync":
-            assert dv > B // 2 and dr <= dv // 20          # a real mismatch is rare even at a 2 % band
+            assert dv > B // 2 and dr <= dv // 20          # a real mismatch is rare even at this band
         if mode == "rollback":
             assert dv > 0 and dr == dv
     for key in ("x", "iters", "status", "step_iters", "wave"):
