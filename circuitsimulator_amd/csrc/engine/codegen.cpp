@@ -118,6 +118,7 @@ bool GeneratorOptions::set(const std::string& keyval)
     if (key == "near_band") { nearBand = std::max(0.0, std::atof(val.c_str())); return true; }
     if (key == "near_band_dc") { nearBandDc = std::max(0.0, std::atof(val.c_str())); return true; }
     if (key == "near_form") { nearForm = std::atoi(val.c_str()) != 0 ? 1 : 0; return true; }
+    if (key == "lds_pad") { ldsPad = std::atoi(val.c_str()) != 0 ? 1 : 0; return true; }
     if (key == "sweep") {
         sweep.clear();
         std::size_t i = 0;
@@ -140,6 +141,7 @@ uint64_t scheduleHash(const csim_ir& ir, const ScheduleSet& set, const Generator
     { uint64_t bits; std::memcpy(&bits, &gopt.nearBand, sizeof bits); mix(bits ^ 0xC2B2AE3D27D4EB4Full); }
     { uint64_t bits; std::memcpy(&bits, &gopt.nearBandDc, sizeof bits); mix(bits ^ 0x165667B19E3779F9ull); }
     mix(static_cast<uint64_t>(gopt.nearForm + 3) * 0x27D4EB2F165667C5ull);
+    mix(static_cast<uint64_t>(gopt.ldsPad + 5) * 0x9E3779B185EBCA87ull);
     for (std::size_t a = 1; a < set.alts.size(); ++a) {
         h ^= 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
         for (int p : set.alts[a].pivotPos) { h ^= static_cast<uint64_t>(p + 1); h *= 1099511628211ull; }

@@ -80,6 +80,7 @@ struct GeneratorOptions {
     // median 9e-11, max 1.2e-9 (relative); DC up to 6e-7 (tol 1e-9 magnifies the solve's rounding).  0 = no guard.
     double nearBand = 2e-8;
     double nearBandDc = 1e-5;
+    int ldsPad = 1;              // sixteen-lane kernels: 1 = per-instance LDS stride padded to 16 (mod 32) doubles, 0 = as it comes
     int nearForm = 0;            // sixteen-lane kernel, how a pass records a near tie: 0 = running minimum of |err - tol| (two
                                  // VALU instructions, one loop-carried double), 1 = two more compares into a loop-carried lane mask
     bool set(const std::string& keyval);      // "barrier_every=3", "sweep=0,16,32", "stage_ahead=3", "pipeline_mos=0", "group_waves=2", "near_band=2e-8", "near_band_dc=1e-5"

@@ -201,7 +201,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     // puts the second group of a pass on the other half of the banks (an odd stride, 847 on dbmixer, overlapped them:
     // SQ_LDS_BANK_CONFLICT was 31 % of the LDS-active cycles, profiles/r02_group16_b4096_summary.md)
     int instDoubles = oST + (nStage + 1) * G;
-    while (instDoubles % 32 != 16) ++instDoubles;
+    while (gopt.ldsPad && instDoubles % 32 != 16) ++instDoubles;
     if (instDoubles * 8 * 4 > 64 * 1024) return std::string();  // keep 2+ waves per CU possible; larger circuits: no group kernel
 
     std::ostringstream o;      // (the shared device code, groupPreludeSource(), is emitted by the caller)

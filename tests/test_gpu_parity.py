@@ -1296,3 +1296,34 @@ def test_auto_jit_through_the_reference_shaped_cli(tmp_path):
     assert a.shape == b.shape and a.shape[0] > 1000
     nl_nodes = a.shape[1] - 1
     assert rel_err(b[:, 1:], a[:, 1:]).max() < 1e-8      # CSV carries 10 significant digits
+
+
+def test_config4_share_of_rank_7(engines, torch_mod):
+    """BASELINE configs[4] (dbmixer.sp, 2^20 Monte-Carlo samples on 8 GPUs): the share of the LAST rank, instances
+    7 * 131 072 ... 8 * 131 072 - 1, 20 time steps on the kernel the engine picks for that batch.  The device's
+    parameter table equals the host mirror at that offset bit for bit; launches cut differently and duplicated
+    columns give the same bits; first / middle / last instance against the oracle; nothing flagged."""
+    torch = torch_mod
+    nl, eng = engines["dbmixer"]
+    B, steps = 131072, 20
+    b_first = 7 * B
+    params = eng.mc_params(12345, 0.05, b_first, B)
+    host = nl.mc_params_host(12345, 0.05, b_first, B)
+    assert np.array_equal(params.cpu().numpy(), host)
+    assert eng.lanes_for_batch(B) == 1                                  # one lane per instance fills the chip at this size
+    one = _run_tran(torch, eng, params, steps, nl.tstep, want_step_iters=True)
+    assert not (one["status"] & 0xA7).any()
+    cut = _run_tran(torch, eng, params, steps, nl.tstep, want_step_iters=True, chunks=[7, 13])
+    for key in ("x", "iters", "step_iters", "status", "dc_iters", "x_dc"):
+        assert np.array_equal(cut[key], one[key]), key
+    dup = params.clone()
+    dup[:, 1::2] = dup[:, 0::2]                                          # every odd column repeats its left neighbour
+    two = _run_tran(torch, eng, dup, steps, nl.tstep)
+    assert np.array_equal(two["x"][:, 1::2], two["x"][:, 0::2]) and np.array_equal(two["iters"][1::2], two["iters"][0::2])
+    assert np.array_equal(two["x"][:, 0::2], one["x"][:, 0::2])           # and a column does not care who its neighbours are
+    for b in (0, B // 2, B - 1):
+        xo, ito, sto = _orc().dc(nl.ir_ptr, nl.n_unknowns, host, b)
+        assert one["dc_iters"][b] == ito and rel_err(one["x_dc"][:, b], xo).max() < TOL
+        o = _orc().tran(nl.ir_ptr, nl.n_unknowns, host, b, nl.tstep, nl.tstep * steps, want_rows=False, want_step_iters=True)
+        assert np.array_equal(one["step_iters"][:, b], o["step_iters"]) and (one["status"][b] & NOFB) == o["status"]
+        assert rel_err(one["x"][:, b], o["x_final"]).max() < TOL
