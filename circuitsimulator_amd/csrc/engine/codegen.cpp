@@ -619,7 +619,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
     else
         src << i2 << "bool active = live;\n"
             << i2 << "int it = 0;\n"
-            << (guard ? i2 + "double nearMin = 1.0;   // smallest |err - tol| of this step's passes\n" : std::string())
+            << (guard ? i2 + "double nearMin = 1.0;   // smallest |ss - tol^2| of this step's passes\n" : std::string())
             << i2 << "for (int iter = 0; iter < " << K.tran_max_iters << "; ++iter) {\n"
             << i2 << "    if (!__any(active)) break;\n";
     // ---- per-iteration terms: MOS channel (device_common.hpp mos_eval)
@@ -942,7 +942,8 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         }
         // a non-finite solve (tanalisis.cpp:360-362) makes ss non-finite; so does an overflow of
         // finite but absurd values -- both are left to the general kernel to classify exactly
-        o << g.ind << "const double err = sqrt(ss);\n"
+        // (guard on: the pass decides on the squared norm, see codegen_group.cpp -- no square root in the loop)
+        o << (guard ? std::string() : g.ind + "const double err = sqrt(ss);\n")
           << g.ind << "if (active) {\n"
           << g.ind << "    if (pv || !(ss < 1.0e300)) { viol = true; active = false; }\n"
           << g.ind << "    else {\n"
@@ -954,13 +955,13 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
         // in the state -- so such a step is treated like a failed pivot check: the lane stops at the step's
         // checkpoint and the bit-faithful general kernel redoes it (and sets CSIM_ST_TRAN_NONCONV if due).
         const int slowIters = slowStepIters(K.tran_tol, K.tran_alpha, K.tran_max_iters);
-        o << g.ind << "        if (err < " << lit(K.tran_tol) << ") active = false;\n";
+        o << g.ind << "        if (" << (guard ? "ss < " + lit(K.tran_tol * K.tran_tol) : "err < " + lit(K.tran_tol)) << ") active = false;\n";
         if (opt.faithful) o << g.ind << "        else if (iter == " << (K.tran_max_iters - 1) << ") st |= ST_TRAN_NONCONV;   // tanalisis.cpp:372-376\n";
         else o << g.ind << "        else if (iter >= " << (slowIters - 1) << ") { viol = true; active = false; }\n";
         if (guard)
             // near-threshold guard: how close did `err < tol` (tanalisis.cpp:369) come to a tie in this step?  Decided
             // once per step, below.
-            o << g.ind << "        nearMin = fmin(nearMin, fabs(err - " << lit(K.tran_tol) << "));\n";
+            o << g.ind << "        nearMin = fmin(nearMin, fabs(ss - " << lit(K.tran_tol * K.tran_tol) << "));\n";
         o
           << g.ind << "    }\n"
           << g.ind << "}\n";
@@ -971,7 +972,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
                 // `err < tol` decided within the rounding noise of this kernel's arithmetic: go on speculatively; the step's
                 // checkpoint is kept and the engine has the faithful kernel verify the pass count.  One checkpoint per
                 // launch: a second such step stops the lane at the start of that step.
-                ? i2 + "const bool nearEvent = live && !viol && nearMin <= " + lit(gopt.nearBand * K.tran_tol) + ";\n"
+                ? i2 + "const bool nearEvent = live && !viol && nearMin <= " + lit(2.0 * gopt.nearBand * K.tran_tol * K.tran_tol) + ";\n"
                   + i2 + "viol = viol || (nearEvent && nearS != 0);\n"
                 : std::string())
             << i2 << "if (live && !viol) {\n"

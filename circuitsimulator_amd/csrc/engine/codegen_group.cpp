@@ -449,7 +449,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     const std::string in = "            ";
     o << "        bool active = live;\n"
       << "        int it = 0;\n"
-      << (guard ? (gopt.nearForm == 0 ? "        double nearMin = 1.0;   // smallest |err - tol| of this step's passes\n"
+      << (guard ? (gopt.nearForm == 0 ? "        double nearMin = 1.0;   // smallest |ss - tol^2| of this step's passes\n"
                                       : "        bool nearAny = false;   // some pass of this step had err within the band around tol\n") : "");
     o << "        for (int iter = 0; iter < " << K.tran_max_iters << "; ++iter) {\n"
       << "            if (!__any(active)) break;\n";
@@ -662,7 +662,11 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     for (int s = 0; s < S; ++s)
         o << in << "{ const double d = xn" << s << " - xo" << s << "; ss += d * d; }\n";
     o << in << "ss = grp_sum16(ss);\n"
-      << in << "const double err = sqrt(ss);\n";
+      // With the guard on, the pass decides on the SQUARED norm: sqrt is monotonic, so `ss < tol^2` and the reference's
+      // `sqrt(ss) < tol` (tanalisis.cpp:366-369) can differ only when ss is within a few ulp of tol^2 -- far inside the
+      // guard band, where the faithful kernel (which takes the root) has the last word.  Saves the 22-instruction
+      // v_rsq_f64 sequence on the critical path of every pass.
+      << (guard ? std::string() : in + "const double err = sqrt(ss);\n");
     if (piped) {
         o << in << "__builtin_amdgcn_sched_barrier(0);      // the norm above ran under the reads of the MOSFET inputs\n";
         emitMos(in);
@@ -672,15 +676,15 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     o << (multi ? std::string() : in + "const bool pv = (__ballot(GRP_PIVOTS_BAD) & rowBits) != 0ull;\n")
       << in << "// branch-free bookkeeping (everything here is uniform within a group of 16 lanes)\n"
       << in << "const bool good = active && !pv && (ss < 1.0e300);      // the solve stands: take the damped update\n"
-      << in << "const bool conv = err < " << lit(K.tran_tol) << ";\n"
+      << in << (guard ? "const bool conv = ss < " + lit(K.tran_tol * K.tran_tol) : "const bool conv = err < " + lit(K.tran_tol)) << ";\n"
       << in << "const bool slow = !conv && iter >= " << (slowIters - 1) << ";                 // slow step: plan.hpp slowStepIters\n";
     if (guard)
         // near-threshold guard: how close did `err < tol` (tanalisis.cpp:369) come to a tie in this step?  Two
         // instructions per pass; everything else happens once per step, below.  (Passes after a group has converged
         // are included: they can only raise a false alarm, which costs a verification and changes nothing.)
         o << in << (gopt.nearForm == 0
-                    ? "nearMin = fmin(nearMin, fabs(err - " + lit(K.tran_tol) + "));\n"
-                    : "nearAny = nearAny || (err > " + lit(K.tran_tol * (1.0 - gopt.nearBand)) + " && err < " + lit(K.tran_tol * (1.0 + gopt.nearBand)) + ");\n");
+                    ? "nearMin = fmin(nearMin, fabs(ss - " + lit(K.tran_tol * K.tran_tol) + "));\n"
+                    : "nearAny = nearAny || (ss > " + lit(K.tran_tol * K.tran_tol * (1.0 - 2.0 * gopt.nearBand)) + " && ss < " + lit(K.tran_tol * K.tran_tol * (1.0 + 2.0 * gopt.nearBand)) + ");\n");
     o << in << "viol = viol || (active && !good) || (good && slow);\n"
       << in << "it += good ? 1 : 0;\n";
     for (int s = 0; s < S; ++s) o << in << "xo" << s << " = good ? xn" << s << " : xo" << s << ";\n";
@@ -705,7 +709,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
         // `err < tol` decided within the rounding noise of this kernel's arithmetic: the group goes on speculatively, the
         // step's start state is kept, and the engine has the faithful kernel verify the step's pass count afterwards.
         // One checkpoint per launch: a second such step stops the group at the start of that step.
-        o << "        const bool nearEvent = live && !viol && " << (gopt.nearForm == 0 ? "nearMin <= " + lit(gopt.nearBand * K.tran_tol) : std::string("nearAny")) << ";\n"
+        o << "        const bool nearEvent = live && !viol && " << (gopt.nearForm == 0 ? "nearMin <= " + lit(2.0 * gopt.nearBand * K.tran_tol * K.tran_tol) : std::string("nearAny")) << ";\n"
           << "        viol = viol || (nearEvent && nearS != 0);\n";
     o << "        if (live && !viol) {\n";
     if (guard) {
