@@ -399,6 +399,12 @@ def main():
             },
             "roofline_valu": valu_roof(iters_per_launch / avg_kern_s, counters, B, 1 if lanes == 64 else lanes, flops_exec)
                              if kernel == "scheduled" else None,
+            # measured HBM bytes against the HBM roof (the figure `roofline` cannot give: its bytes are the dense system's)
+            "hbm_measured": ({"bytes_per_launch": counters["hbm_bytes_per_unit"] * iters_per_launch,
+                              "achieved_GBs": counters["hbm_bytes_per_unit"] * iters_per_launch / avg_kern_s / 1e9,
+                              "frac_of_peak": counters["hbm_bytes_per_unit"] * iters_per_launch / avg_kern_s / 1e9 / HBM_PEAK_GBS,
+                              "source": counters.get("source")}
+                             if counters and counters.get("hbm_bytes_per_unit") else None),
             # the dense LU + substitution flops the reference spends per NR iteration,
             # n(n-1)/2 + (n-1)n(2n-1)/3 + 2n(n-1) + n, against the FP64 vector peak (the kernels execute far fewer:
             # structural zeros are never touched)

@@ -143,6 +143,8 @@ void adoptScheduleTable(csim_engine* eng, void* lib)
     typedef int (*LanesFn)(void);
     LanesFn lanesFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_group_lanes"));
     eng->schedGroupLanes = lanesFn ? lanesFn() : 0;
+    LanesFn linFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_linear_lanes"));
+    eng->schedLinearLanes = linFn ? linFn() : 0;
     LanesFn faithFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_has_faithful"));
     eng->schedHasFaithful = faithFn && faithFn() != 0;
     if (eng->kernelChoice == 3 && !eng->schedHasFaithful) eng->kernelChoice = 0;    // a reload dropped the faithful kernel
@@ -403,6 +405,7 @@ static int schedVariantFor(const csim_engine* eng, int32_t B)
 extern "C" int csim_engine_lanes_for_batch(const csim_engine* eng, int32_t B)
 {
     if (!eng || !eng->schedLaunch || eng->kernelChoice == 1) return 0;
+    if (eng->schedLinearLanes) return eng->schedLinearLanes;       // a linear circuit's library has one transient kernel
     return schedVariantFor(eng, B) == 16 ? 16 : 1;
 }
 

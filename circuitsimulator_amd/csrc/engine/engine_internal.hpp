@@ -71,6 +71,7 @@ struct csim_engine {
     int schedWorkCap = 0;                  // instances
     bool schedHasFaithful = false;         // the library carries csim_tran_faithful_kernel (launch variant 3)
     int schedGroupLanes = 0;               // 16 when the library also carries the sixteen-lanes-per-instance kernel
+    int schedLinearLanes = 0;              // linear-circuit library: lanes per instance of its kernel (16 or 1), else 0
     int32_t* dKnownAlts = nullptr;         // [nKnownAlts][N] pivot sequences the loaded kernel carries
     int nKnownAlts = 0;
     unsigned char* dFallback = nullptr;    // per-instance reason an instance left a generated kernel (codegen.cpp csim_sched_aux)

@@ -125,7 +125,8 @@ const char* csim_engine_tran_kernel(const csim_engine* eng);
  * ("ops_per_solve: fma=.. mul=.. addsub=.. recip=.. cmp=..")                                   */
 const char* csim_engine_sched_info(const csim_engine* eng);
 /* lanes per instance the scheduled transient kernel would use for a batch of B instances (1 or 16;
- * 0 = the general kernel runs: one 64-lane wavefront per instance)                              */
+ * 0 = the general kernel runs: one 64-lane wavefront per instance).  A linear circuit's library has one
+ * transient kernel: 16 (tape and iterate in registers) or 1 (larger circuits), whatever B is.        */
 int  csim_engine_lanes_for_batch(const csim_engine* eng, int32_t B);
 /* force a kernel family: 0 = auto, 1 = general only, 2 = scheduled required, 3 = the generated kernel
  * with the reference's arithmetic ("faithful": true divisions, no FMA contraction, steps at the NR cap

@@ -12,6 +12,10 @@ cd "$R"
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 echo "bench args: $ARGS" > "$OUT/command.txt"
+# one un-profiled run first: it fills the JIT cache (a netlist without a shipped kernel library is specialised with
+# hipcc on first use), so that no compiler is started from under the profiler (the engine also strips the profiler's
+# preload from the compiler's environment, jit.cpp)
+timeout -k 10 600 python3 bench.py $ARGS > "$OUT/bench_warm.json" 2> "$OUT/warm.err" || echo "warm-up run failed"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err" || echo "trace pass failed"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE SQ_WAVES TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo $pass | tr ' ' '+')
