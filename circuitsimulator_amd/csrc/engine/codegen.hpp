@@ -80,14 +80,17 @@ struct GeneratorOptions {
     // median 9e-11, max 1.2e-9 (relative); DC up to 6e-7 (tol 1e-9 magnifies the solve's rounding).  0 = no guard.
     double nearBand = 2e-8;
     double nearBandDc = 1e-5;
-    int ldsPad = 1;              // sixteen-lane kernels: 1 = per-instance LDS stride padded to 16 (mod 32) doubles, 0 = as it comes
+    int ldsPad = 0;              // sixteen-lane kernels: 1 = per-instance LDS stride padded to 16 (mod 32) doubles, 0 = as it comes
+                                 // (measured, profiles/r03_group16_b4096_*: SQ_LDS_BANK_CONFLICT 30.9 % of the LDS-active cycles
+                                 // either way -- the conflicts come from the per-lane gathers / scatters of the MOSFET pass, not
+                                 // from the [row][16] reads -- and 0.8 % slower padded)
     int nearForm = 0;            // sixteen-lane kernel, how a pass records a near tie: 0 = running minimum of |err - tol| (two
                                  // VALU instructions, one loop-carried double), 1 = two more compares into a loop-carried lane mask
     bool set(const std::string& keyval);      // "barrier_every=3", "sweep=0,16,32", "stage_ahead=3", "pipeline_mos=0", "group_waves=2", "near_band=2e-8", "near_band_dc=1e-5"
 };
 
 // bumped whenever the emitted code or the launcher ABI of a generated library changes
-constexpr int kGeneratorRevision = 26;
+constexpr int kGeneratorRevision = 27;
 
 // identifies (topology, constants, schedule); names the generated library
 uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch);

@@ -196,10 +196,10 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     // LDS carve-up per instance (doubles)
     const int nT1 = ap.nTerms + 1;                              // + one dummy term (always 0) for padded table entries
     const int oXS = 0, oXP = oXS + NP + 1, oTT = oXP + NP + 1, oTS = oTT + nT1, oPL = oTS + 2 * nT1, oST = oPL + ir.n_params;
-    // Per-instance stride: the four groups of a wave read the same [row][16] cells of their own instance in one
-    // ds_read_b64, 32 lanes (two groups) per pass over the 64 four-byte banks: a stride of 16 doubles (mod 32)
-    // puts the second group of a pass on the other half of the banks (an odd stride, 847 on dbmixer, overlapped them:
-    // SQ_LDS_BANK_CONFLICT was 31 % of the LDS-active cycles, profiles/r02_group16_b4096_summary.md)
+    // Per-instance stride (generator option lds_pad): the four groups of a wave read the same [row][16] cells of their
+    // own instance in one ds_read_b64, 32 lanes (two groups) per pass over the 64 four-byte banks; a stride of 16
+    // doubles (mod 32) puts the second group of a pass on the other half of the banks.  Measured: no fewer conflicts
+    // (codegen.hpp), so off by default.
     int instDoubles = oST + (nStage + 1) * G;
     while (gopt.ldsPad && instDoubles % 32 != 16) ++instDoubles;
     if (instDoubles * 8 * 4 > 64 * 1024) return std::string();  // keep 2+ waves per CU possible; larger circuits: no group kernel

@@ -893,9 +893,10 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
             bzero[sz(P)] = 0;
         }
     }
-    ch << in << "// back substitution (solver.hpp:116-128): row i = N-1 .. 0, columns j ascending; x_i replaces b_i in place\n";
+    ch << in << "// back substitution (solver.hpp:116-128): row i = N-1 .. 0, columns j ascending\n";
+    std::vector<char> xzero(sz(N), 0);
+    std::vector<std::string> xq(sz(N));
     {
-        std::vector<char> xzero(sz(N), 0);
         for (int i = N - 1; i >= 0; --i) {
             int lastJ = -1;
             std::string xb;
@@ -904,7 +905,7 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
                 if (u.zero() || xzero[sz(j)]) continue;
                 if (u.kind == LV::DYN && cnt[sz(j % G)] < cnt[sz(i % G)]) {       // operand in the lane of x_j: see the forward pass
                     const std::string pt = "up" + std::to_string(tmp++), t = "ut" + std::to_string(tmp++);
-                    ch << in << "const double " << pt << " = " << take(u, j % G) << " * " << W(j) << ";\n"
+                    ch << in << "const double " << pt << " = " << take(u, j % G) << " * " << xq[sz(j)] << ";\n"
                        << in << "const double " << t << " = grp_bc<" << j % G << ">(" << pt << ");\n"
                        << in << W(i) << " = fma(-" << t << ", " << MK(i) << ", " << W(i) << ");\n";
                     nChainInstr += 3;
@@ -913,7 +914,7 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
                 }
                 if (lastJ != j) {
                     xb = "xb" + std::to_string(tmp++);
-                    ch << in << "const double " << xb << " = grp_bc<" << j % G << ">(" << W(j) << ");\n";
+                    ch << in << "const double " << xb << " = grp_bc<" << j % G << ">(" << xq[sz(j)] << ");\n";
                     lastJ = j;
                     ++nChainInstr;
                 }
@@ -928,20 +929,15 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
                 ++nChainInstr;
                 bzero[sz(i)] = 0;
             }
-            const LV& pv = F.piv[sz(i)];
-            if (bzero[sz(i)]) { xzero[sz(i)] = 1; continue; }         // x_i = 0 / U(i,i): an exact zero, w already holds one
-            if (pv.kind == LV::CONST) {
-                if (pv.c == 1.0) continue;
-                const std::string q = "xq" + std::to_string(tmp++);
-                ch << in << "const double " << q << " = " << (pv.c == -1.0 ? "-" + W(i) : W(i) + " / " + lit(pv.c)) << ";\n"
-                   << in << W(i) << " = (g == " << i % G << ") ? " << q << " : " << W(i) << ";\n";
-                nChainInstr += 3;
-                continue;
-            }
-            const std::string pe = take(pv, i % G), re = take(F.rinv[sz(i)], i % G), q = "xq" + std::to_string(tmp++);
-            ch << in << "const double " << q << " = lin_quot(" << W(i) << ", " << pe << ", " << re << ");\n"
-               << in << W(i) << " = (g == " << i % G << ") ? " << q << " : " << W(i) << ";\n";
-            nChainInstr += 5;
+            // x_i = sum / U(i,i) (:126).  Every lane owns exactly one pivot per slot, so pivots and their reciprocals sit in
+            // slot-aligned registers (pv<s>, ri<s>) and the quotient is formed by ALL lanes at once; only lane i % 16 holds a
+            // finished sum here, and only that lane's quotient is read (by the broadcasts of the rows above).  w keeps the
+            // sums: the quotients of all rows are formed once more, slot by slot, after the chain (same inputs, same bits),
+            // which spares a 64-bit select per row on the chain's critical path.
+            if (bzero[sz(i)]) { xzero[sz(i)] = 1; continue; }         // x_i = 0 / U(i,i): an exact zero
+            ch << in << "const double xq" << i << " = QUOT" << i / G << "(" << W(i) << ");\n";
+            nChainInstr += 3;
+            xq[sz(i)] = "xq" + std::to_string(i);
         }
     }
     int Tmax = 0;
@@ -949,10 +945,22 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
     if (Tmax == 0) Tmax = 1;
     // registers: tape + x + w + the sixteen masks, two VGPRs each, and ~70 for addresses, descriptors and temporaries
     if (std::getenv("CSIM_CG_DEBUG")) std::fprintf(stderr, "linear16: N=%d S=%d Tmax=%d chain instructions=%d hist rounds=%d\n", N, S, Tmax, nChainInstr, histRounds);
-    if (2 * (Tmax + 2 * S + G) + 70 > 500) return std::string();
+    if (2 * (Tmax + 4 * S + G) + 70 > 500) return std::string();
     std::vector<int> zeroFill = idleHist;
     for (int g = 0; g < G; ++g)
         for (int r = std::max(cnt[sz(g)], 0); r < Tmax; ++r) zeroFill.push_back(r * G + g);
+    // pivots and reciprocals, slot-aligned: entries (Tmax + 2 s) * 16 + g and (Tmax + 2 s + 1) * 16 + g hold U(p,p) and 1 / U(p,p)
+    // of the row at final position p = 16 s + g; exact constants are written as literals, padding lanes get 1 (w there is 0)
+    std::vector<std::pair<int, double>> constFill;
+    for (int p = 0; p < NP; ++p) {
+        const int ip = (Tmax + 2 * (p / G)) * G + p % G, ir_ = ip + G;
+        if (p >= N) { constFill.push_back({ip, 1.0}); constFill.push_back({ir_, 1.0}); continue; }
+        const LV& pv = F.piv[sz(p)];
+        if (pv.kind == LV::CONST) { constFill.push_back({ip, pv.c}); constFill.push_back({ir_, 1.0 / pv.c}); continue; }
+        if (handleOf(pv) < 0 || handleOf(F.rinv[sz(p)]) < 0) return std::string();      // cannot happen: a run-time pivot is parked
+        uses[sz(handleOf(pv))].push_back(ip);
+        uses[sz(handleOf(F.rinv[sz(p)]))].push_back(ir_);
+    }
 
     // ---- tables
     auto intArray = [](const std::string& name, const std::vector<int32_t>& v) {
@@ -980,7 +988,6 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
 
     const int oXP = 0, oTS = oXP + NP + 1;
     int instDoubles = oTS + 2 * (nStep + 2);
-    while (instDoubles % 32 != 16) ++instDoubles;       // bank halves for the two groups of a 32-lane LDS pass (codegen_group.cpp)
     if (instDoubles * 8 * 4 > 40 * 1024) return std::string();           // four workgroups per CU (one wave per SIMD)
 
     std::ostringstream o;
@@ -1010,6 +1017,7 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
       << resolveFactorText(F.text, uses)
       << "    viol = viol || pvF != 0;\n";
     for (int n : zeroFill) o << "    TW(" << n << ") = 0.0;\n";
+    for (const auto& cf : constFill) o << "    TW(" << cf.first << ") = " << lit(cf.second) << ";\n";
     o << "    if (inb && viol) fallback[b] = 1;     // no recorded pivot sequence fits: the general kernel runs this launch\n"
       << "#undef TW\n#undef TF\n"
       << "}\n\n";
@@ -1035,6 +1043,11 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
     for (int t = 0; t < G; ++t) o << "    const double mk" << t << " = (g == " << t << ") ? 1.0 : 0.0;\n";
     o << "    // the tape: this lane's operands in its order of use\n";
     for (int r = 0; r < Tmax; ++r) o << "    const double tp" << r << " = work[(long long)(" << r * G << " + g) * SBW + bb];\n";
+    o << "    // this lane's pivots and their reciprocals, one per slot (solver.hpp:126 divides by the pivot)\n";
+    for (int s = 0; s < S; ++s)
+        o << "    const double pv" << s << " = work[(long long)(" << (Tmax + 2 * s) * G << " + g) * SBW + bb], ri" << s
+          << " = work[(long long)(" << (Tmax + 2 * s + 1) * G << " + g) * SBW + bb];\n"
+          << "#define QUOT" << s << "(v) lin_quot((v), pv" << s << ", ri" << s << ")\n";
     for (int r = 0; r < srcRounds; ++r)
         o << "    const int se" << r << " = l16_src[" << r * G << " + g];       // source evaluated by this lane in round " << r << " (-1: none)\n"
           << "    const int sq" << r << " = se" << r << " >= 0 ? se" << r << " : 0;\n"
@@ -1093,7 +1106,9 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
         for (int t = 0; t < rhsMax[sz(s)]; ++t) o << "        w" << s << " += rt" << s << "_" << t << ";\n";
     }
     o << ch.str()
-      << "        // Newton passes: x_raw is the same in every pass of the step; damped update, norm, convergence\n"
+      << "        // x_raw: every lane's finished sum over its pivot, all rows of a slot at once\n";
+    for (int s = 0; s < S; ++s) o << "        w" << s << " = QUOT" << s << "(w" << s << ");\n";
+    o << "        // Newton passes: x_raw is the same in every pass of the step; damped update, norm, convergence\n"
       << "        // (tanalisis.cpp:365-376) are executed pass by pass.  A group that is done keeps its iterate through a\n"
       << "        // zero step length (x + 0 * (x_raw - x) == x), not a branch.\n"
       << "        bool active = live;\n"
@@ -1103,7 +1118,8 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
       << "            const double al = active ? " << lit(K.tran_alpha) << " : 0.0;\n"
       << "            double ss = 0.0;\n";
     for (int s = 0; s < S; ++s)
-        o << "            { const double xn = x" << s << " + al * (w" << s << " - x" << s << "); const double d = xn - x" << s << "; ss += d * d; x" << s << " = xn; }\n";
+        // (the squares are accumulated with fma: like the order of this sum, that touches the threshold's last bits only)
+        o << "            { const double xn = x" << s << " + al * (w" << s << " - x" << s << "); const double d = xn - x" << s << "; ss = fma(d, d, ss); x" << s << " = xn; }\n";
     o << "            ss = grp_sum16(ss);\n"
       << "            const double err = sqrt(ss);\n"
       << "            const bool good = active && (ss < 1.0e300);      // else: a non-finite solve, the general kernel classifies it\n"
@@ -1136,9 +1152,11 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
       << "            if (sdone < nSteps) violFlag[0] = 1;\n"
       << "        }\n"
       << "    }\n"
-      << "}\n#pragma clang fp contract(fast)\n\n";
+      << "}\n";
+    for (int s = 0; s < S; ++s) o << "#undef QUOT" << s << "\n";
+    o << "#pragma clang fp contract(fast)\n\n";
     (void)nChainInstr;
-    if (workDoubles) *workDoubles = Tmax * G;
+    if (workDoubles) *workDoubles = (Tmax + 2 * S) * G;
     return o.str();
 }
 

@@ -100,6 +100,29 @@ __device__ bool gs_sweeps_lane0(const double* Gm, int N, int LD, const int32_t* 
     return true;
 }
 
+// The reference's dense loops, every j != i, no early exit (include/solver.hpp:162-193): what dcSolveDirectGS returns
+// when the sweeps diverge is whatever they left -- a mix of +-inf and NaN that depends on the order in which the
+// non-finite values spread, structural zeros included (0 * inf = NaN).  Lane 0, only after gs_sweeps_lane0 gave up.
+__device__ void gs_sweeps_dense_lane0(const double* Gm, int N, int LD, const double* xs, double* xr, double* xo,
+                                      int maxIters, double tol)
+{
+    for (int i = 0; i < N; ++i) xr[i] = xs[i];
+    for (int iter = 0; iter < maxIters; ++iter) {
+        for (int i = 0; i < N; ++i) xo[i] = xr[i];
+        for (int i = 0; i < N; ++i) {
+            double diag = Gm[i * LD + i];
+            if (fabs(diag) < 1e-12) diag = (diag >= 0.0 ? 1.0 : -1.0) * 1e-12;
+            double sum = Gm[i * LD + N];
+            for (int j = 0; j < i; ++j) sum -= Gm[i * LD + j] * xr[j];
+            for (int j = i + 1; j < N; ++j) sum -= Gm[i * LD + j] * xo[j];
+            xr[i] = sum / diag;
+        }
+        double ss = 0.0;
+        for (int i = 0; i < N; ++i) { const double d = xr[i] - xo[i]; ss += d * d; }
+        if (sqrt(ss) < tol) break;
+    }
+}
+
 } // namespace
 
 __global__ void __launch_bounds__(64)
@@ -141,15 +164,14 @@ k_dc_gs(GenPlan pl, const int32_t* __restrict__ rowPtr, const int32_t* __restric
         wave_sync();
         assemble(pl, T, Gm, lane);
         if (lane == 0) {
-            // the reference returns whatever the sweeps left, finite or not: dense continuation is
-            // not needed for the vector to be reported as non-finite, but its VALUES would differ;
-            // a linear DC solve that diverges is flagged and returns NaN in every component, which
-            // is what the dense loops converge to after one more sweep
-            *flag = gs_sweeps_lane0(Gm, N, LD, rowPtr, rowCol, xs, xr, xo, gsSweeps, gsTol) ? 1 : 0;
+            // the reference returns whatever the sweeps left, finite or not, and checks nothing (:89-91): when the
+            // sparse sweeps meet a non-finite value the solve is redone with the reference's dense loops, whose
+            // pattern of +-inf / NaN is then the reference's, component by component
+            if (!gs_sweeps_lane0(Gm, N, LD, rowPtr, rowCol, xs, xr, xo, gsSweeps, gsTol))
+                gs_sweeps_dense_lane0(Gm, N, LD, xs, xr, xo, gsSweeps, gsTol);
         }
         wave_sync();
-        if (lane < N) xs[lane] = *flag ? xr[lane] : __builtin_nan("");
-        if (!*flag) st |= CSIM_ST_DC_NONFINITE;
+        if (lane < N) xs[lane] = xr[lane];
         itTotal = 1;
     } else {
         for (int step = 1; step <= K.dc_ramp_steps; ++step) {                       // :183

@@ -246,7 +246,9 @@ int  csim_gs_solve_batch(int32_t device, int32_t n, int32_t B, const double* A, 
  * Gauss-Seidel solve (2000 sweeps, 1e-10), circuits with MOSFETs the source ramp with 60 (last step 120)
  * Newton passes per step, inner solve warm-started from x, ConvController update.  A pass whose inner
  * solve turns non-finite raises gmin x10 and is dropped (CSIM_ST_DC_NONFINITE), exactly as upstream; on
- * circuits with voltage sources (zero diagonal entries) that is every pass and x stays 0.  N <= 63.   */
+ * circuits with voltage sources (zero diagonal entries) that is every pass and x stays 0.  A LINEAR
+ * circuit whose sweeps diverge returns what the reference's dense loops leave (a pattern of +-inf / NaN,
+ * reproduced component by component) and no flag -- upstream checks nothing there (:89-91).  N <= 63.   */
 int  csim_dc_gs_batch_dev(csim_engine* eng, const double* d_params /*[P][B]*/, int32_t B,
                           double* d_x /*[N][B]*/, int32_t* d_iters, uint32_t* d_status, void* stream);
 int  csim_dc_gs_batch(csim_engine* eng, const double* params /*[B][P] or NULL*/, int32_t B,
