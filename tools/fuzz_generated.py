@@ -28,6 +28,7 @@ def main():
     from circuitsimulator_amd import Engine, Netlist
     bad = 0
     n_fb = 0
+    n_ver = 0
     for seed in range(a.first, a.first + a.count):
         rs = np.random.RandomState(seed)
         nl = Netlist.from_text(t._random_netlist(rs, rs.randint(3, 25), rs.randint(0, 8)))
@@ -40,25 +41,30 @@ def main():
         except Exception as e:
             print("seed %d N=%d: JIT refused: %s" % (seed, nl.n_unknowns, e), flush=True)
             continue
-        fast = t._run_tran(torch, eng, params, steps, nl.tstep, want_step_iters=True)
         clean = (slow["status"] == 0)                    # converged instances: the strict bar applies
         problems = []
-        if not np.array_equal(fast["dc_iters"][clean], slow["dc_iters"][clean]):
-            problems.append("dc iters")
-        if not np.array_equal(fast["step_iters"][:, clean], slow["step_iters"][:, clean]):
-            problems.append("tran iters")
-        if not np.array_equal((fast["status"] & t.NOFB)[clean], slow["status"][clean]):
-            problems.append("status")
-        if clean.any():
-            e = t.rel_err(fast["x"].T[clean], slow["x"].T[clean]).max()
-            if e >= t.TOL:
-                problems.append("x deviates %.2e" % e)
-        n_fb += int(((fast["status"] & 0xA0) != 0).sum())
+        for dc_fast in (0, 1):                           # the faithful generated DC kernel (default) and the fast, guarded one
+            eng.set_option("dc_fast", dc_fast)
+            fast = t._run_tran(torch, eng, params, steps, nl.tstep, want_step_iters=True)
+            tag = " (dc_fast)" if dc_fast else ""
+            if not np.array_equal(fast["dc_iters"][clean], slow["dc_iters"][clean]):
+                problems.append("dc iters" + tag)
+            if not np.array_equal(fast["step_iters"][:, clean], slow["step_iters"][:, clean]):
+                problems.append("tran iters" + tag)
+            if not np.array_equal((fast["status"] & t.NOFB)[clean], slow["status"][clean]):
+                problems.append("status" + tag)
+            if clean.any():
+                e = t.rel_err(fast["x"].T[clean], slow["x"].T[clean]).max()
+                if e >= t.TOL:
+                    problems.append("x deviates %.2e%s" % (e, tag))
+            n_fb += int(((fast["status"] & 0xA0) != 0).sum())
+        n_ver += eng.stat("near_verified")
         if problems:
             bad += 1
             print("seed %d N=%d (%d clean of %d): %s" % (seed, nl.n_unknowns, int(clean.sum()), B, "; ".join(problems)), flush=True)
         eng.close()
-    print("fuzz: %d circuits, %d with mismatches, %d instance runs replayed by the general kernels" % (a.count, bad, n_fb))
+    print("fuzz: %d circuits (each with the faithful and with the fast DC kernel), %d with mismatches, %d instance runs "
+          "replayed by the general kernels, %d near-threshold decisions verified" % (a.count, bad, n_fb, n_ver))
     sys.exit(1 if bad else 0)
 
 
