@@ -133,3 +133,23 @@ def test_generated_dbmixer_kernel_register_allocation(codegen, tmp_path):
     assert lean["private_segment_fixed_size"] <= 320, lean         # bytes of scratch per lane (shipped: 180)
     assert lean["vgpr_spill_count"] <= 80, lean                    # shipped: 44
     assert meta["csim_dc_sched_kernel"]["private_segment_fixed_size"] == 0
+
+
+def test_generated_source_changes_only_with_a_new_generator_revision(codegen):
+    """kGeneratorRevision is part of the hash a cached / shipped library is checked against (codegen.cpp scheduleHash):
+    emitted code that changes without a new revision would let a stale JIT cache entry pass for a current one.  The
+    golden record (tools/update_generated_golden.py) holds the md5 of the generator's output for the two shipped
+    schedules and the revision it was taken at."""
+    import importlib.util
+    import json
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("upd", os.path.join(ROOT, "tools", "update_generated_golden.py"))
+    upd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(upd)
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "generated_source.json")))
+    now = upd.digests()
+    if now != golden["source_md5"]:
+        assert upd.revision() != golden["generator_revision"], \
+            "the generator's output changed but kGeneratorRevision (codegen.hpp) did not: bump it"
+        pytest.fail("generator output and revision changed: record them with tools/update_generated_golden.py")
+    assert upd.revision() == golden["generator_revision"], "revision bumped without a change of the emitted code: re-record"
