@@ -31,6 +31,19 @@
  * points take the instance-major tables proposed in SURVEY.md 8(b) ([B][P],
  * [B][N]) and do the copies and transposes.
  *
+ * Arithmetic.  The general kernels, the "faithful" generated kernels (transient and DC) and the kernels for
+ * linear circuits perform the reference's floating-point operations in the reference's order (the device's
+ * sin() may differ from glibc's in the last bit).  The FAST generated transient kernels (family "scheduled":
+ * one and sixteen lanes per instance) deviate deliberately, inside the 1e-9 bar, NR counts equal: FMA
+ * contraction; one refined reciprocal per pivot instead of a division per multiplier; sixteen-lane kernel:
+ * matrix assembled as (step-constant part) + (MOSFET part), back substitution in descending column order, the
+ * recorded pivot accepted where a LATER row exceeds it by less than 8 ulp (the reference would swap: the two
+ * pivots then agree to 15 digits; include/solver.hpp:48-56), the update norm summed across lanes; convergence
+ * decided on the squared norm.  A convergence decision within 2e-8 (relative) of its threshold is re-done by
+ * the faithful kernel and rolled back if it falls the other way; steps that do not contract at the damping
+ * rate, and factorisations no recorded pivot sequence fits, are handed to the faithful / general kernels.
+ * csim_engine_set_kernel(eng, 3) selects the faithful family outright.
+ *
  * Streams.  With the default option hybrid_sync = 1 a *_dev call that runs
  * generated ("scheduled") kernels WAITS on its stream once per stage of the
  * hand-over ladder to read two flag words -- usually once per call -- and
