@@ -138,6 +138,29 @@ def self_launch(n):
     return 0
 
 
+def cpu_share():
+    """CPUs this process may USE: its affinity mask, cut down to the cgroup's CPU quota when there is one (a GPU box
+    gives one GPU's job a share of the host: 256 cores visible, 16 cores' worth of time -- 256 threads then run slower
+    than 16)."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:                                                   # cgroup v2
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:                                               # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.999)))
+    return n, quota
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -434,9 +457,9 @@ def main():
         if world == 1 and not args.no_cpu:
             # CPU baseline: the oracle (port of the reference algorithm), 1 thread,
             # on the first instances of the same parameter table
-            ncores = len(os.sched_getaffinity(0))
-            nthr = ncores if args.cpu_threads <= 0 else max(1, min(ncores, args.cpu_threads))
-            ph = params[:, :min(B, max(256, 64 * nthr))].cpu().numpy()
+            ncores, quota = cpu_share()
+            nthr = ncores if args.cpu_threads <= 0 else max(1, min(len(os.sched_getaffinity(0)), args.cpu_threads))
+            ph = params[:, :min(B, 1024)].cpu().numpy()
             s_cpu = min(S * args.steps, 2000)                  # bounded sample: at most 2000 time steps per instance
             est_per_inst = 10.0 * s_cpu
             n_cpu = int(max(1, min(ph.shape[1], round(args.cpu_iters / est_per_inst))))
@@ -448,20 +471,27 @@ def main():
                 "kind": "port",
                 "cpu_model": cpu_model(),
                 "sample": "oracle/mna_oracle.c, instances 0..%d of the same table, %d time steps from the DC "
-                          "point (%d NR iterations, %.1f s, host has %d cores, %d usable by this process)"
-                          % (n_cpu - 1, s_cpu, ci, cdt, os.cpu_count() or 0, ncores),
+                          "point (%d NR iterations, %.1f s, host has %d cores, affinity %d, cgroup CPU quota %s)"
+                          % (n_cpu - 1, s_cpu, ci, cdt, os.cpu_count() or 0, len(os.sched_getaffinity(0)),
+                             ("%.1f cores" % quota) if quota is not None else "none"),
             }
             # the same port on ALL host cores this process may run on (one thread per core over
             # instances; the C call releases the GIL), a second bounded sample sized for ~cpu_seconds of wall time
             if nthr > 1:
+                # thread counts tried: every CPU this process may use, and -- when that is more than 16 -- the 16 a one-GPU
+                # job is given on this pool (a share the cgroup files do not always show: 256 threads on a 16-core share
+                # measured 1.8e6, 16 threads 3.9e6); the better one is reported, both are kept
                 per_inst_s = cdt / n_cpu
-                n_mt = int(max(nthr, min(ph.shape[1], round(args.cpu_seconds * nthr / per_inst_s))))
-                mi, mdt = cpu_baseline(nl, ph, n_mt, tstep, s_cpu, threads=nthr)
-                rec["cpu_baseline"]["all_cores"] = {
-                    "value": mi / mdt, "cores": nthr, "host_cores": os.cpu_count() or 0,
-                    "sample": "instances 0..%d, %d time steps (%d NR iterations, %.1f s, %d threads)"
-                              % (n_mt - 1, s_cpu, mi, mdt, nthr),
-                }
+                tried = []
+                for thr in sorted({nthr, min(nthr, 16)}):
+                    n_mt = int(max(thr, min(ph.shape[1], 1024, round(args.cpu_seconds * thr / per_inst_s))))
+                    mi, mdt = cpu_baseline(nl, ph, n_mt, tstep, s_cpu, threads=thr)
+                    tried.append({"value": mi / mdt, "cores": thr,
+                                  "sample": "instances 0..%d, %d time steps (%d NR iterations, %.1f s, %d threads)"
+                                            % (n_mt - 1, s_cpu, mi, mdt, thr)})
+                best = max(tried, key=lambda t: t["value"])
+                rec["cpu_baseline"]["all_cores"] = dict(best, host_cores=os.cpu_count() or 0, usable_cores=nthr,
+                                                        cgroup_cpu_quota_cores=quota, tried=tried)
         print(json.dumps(rec))
 
     import torch.distributed as dist

@@ -575,8 +575,7 @@ int csim_tran_batch_dev(csim_engine* eng, const double* d_params, int32_t B, dou
     // cfg.hybridSync (default): the host reads the flags after each stage and returns as soon as nothing is
     // left.  With hybrid_sync = 0 the call never waits: the same sequence of launches is enqueued
     // unconditionally (every kernel returns at once when it finds nothing to do; 10 launches per hybrid round,
-    // a few microseconds each) -- bit for bit the synchronous results, for callers that overlap streams or
-    // capture graphs.
+    // a few microseconds each) -- bit for bit the synchronous results, for callers that overlap streams.
     {
         const int rc = ensureFallbackBuffers(eng, B);
         if (rc) return rc;

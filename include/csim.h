@@ -50,7 +50,10 @@
  * returns as soon as no instance is left unfinished.  With hybrid_sync = 0
  * such a call only enqueues (a fixed sequence of launches, each returning at
  * once when it finds nothing to do) and never waits: use that to overlap
- * streams or to capture a HIP graph.  Calls on engines without a generated
+ * streams (copies or collectives of one launch's results under the next launch).
+ * Graph capture is NOT supported (step_first is a kernel argument, and a replayed
+ * capture did not reproduce a direct call reliably: tools/dev/graph_capture_probe.py).
+ * Calls on engines without a generated
  * kernel never wait.  An engine owns ONE set of hand-over buffers: calls on
  * the same engine must be ordered with respect to each other (same stream, or
  * event-ordered); use one engine per concurrent stream.
