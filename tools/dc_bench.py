@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Times the DC operating point of tests/dbmixer.sp Monte-Carlo batches with the general (wave per
-instance) and the scheduled (lane per instance) kernel.  Run under rocprofv3 --kernel-trace --stats
+"""Times the DC operating point of tests/dbmixer.sp Monte-Carlo batches with the general kernel, the faithful
+generated kernel (the engine's default) and the fast generated kernel (option dc_fast).  Run under rocprofv3 --kernel-trace --stats
 for profiles/r01_dc_kernel_stats.csv.
 
     python tools/dc_bench.py [--batch 4096 131072]
@@ -27,8 +27,9 @@ def main():
     for B in a.batch:
         params = eng.mc_params(12345, 0.05, 0, B)
         rec = {"batch": B}
-        for kern in ("general", "auto"):
-            eng.set_kernel(kern)
+        for kern in ("general", "auto", "fast"):
+            eng.set_kernel("general" if kern == "general" else "auto")
+            eng.set_option("dc_fast", 1 if kern == "fast" else 0)
             x, it, st = eng.dc(params)          # warm-up
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -37,7 +38,7 @@ def main():
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / a.reps
             total = int(it.sum().item())
-            rec[kern if kern == "general" else "scheduled"] = {
+            rec[{"general": "general", "auto": "faithful_generated", "fast": "fast_generated"}[kern]] = {
                 "ms": 1e3 * dt, "nr_iters": total, "nr_iter_inst_per_s": total / dt,
                 "replayed_by_general": int((st & 0x80).ne(0).sum().item()),
                 "flagged": int((st & 0x1F).ne(0).sum().item())}
