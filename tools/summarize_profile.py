@@ -31,7 +31,13 @@ def main():
     n_steps = bench["steps"] + bench["warmup"] + int(bench["config"].get("setup_probe_steps", 0))
 
     # kernel-trace stats (only this repo's kernels + the total)
-    stats = list(csv.DictReader(open(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0])))
+    # (gpurun merges a call's files into gpurun_out/: an earlier profile of the same tag leaves its files next to the
+    # new ones -- always take the newest)
+    def newest(pattern):
+        fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+        return fs[-1:] if fs else []
+
+    stats = list(csv.DictReader(open(newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0])))
     ours = [r for r in stats if "csim" in r["Name"]]
     with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as f:
         w = csv.writer(f)
@@ -44,7 +50,7 @@ def main():
     pmc = collections.defaultdict(dict)
     meta = {}
     for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
-        fs = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+        fs = newest(os.path.join(d, "*", "*_counter_collection.csv"))
         if not fs:
             continue
         acc = collections.defaultdict(list)
