@@ -42,7 +42,10 @@
  * decided on the squared norm.  A convergence decision within 2e-8 (relative) of its threshold is re-done by
  * the faithful kernel and rolled back if it falls the other way; steps that do not contract at the damping
  * rate, and factorisations no recorded pivot sequence fits, are handed to the faithful / general kernels.
- * csim_engine_set_kernel(eng, 3) selects the faithful family outright.
+ * What remains: a step whose update norm lands within ~1e-9 of the tolerance is decided by the last bits of the
+ * whole trajectory; measured on dbmixer.sp, a fast family takes one NR pass more or less than the faithful
+ * family about once per 1e10 step decisions.  csim_engine_set_kernel(eng, 3) selects the
+ * faithful family outright.
  *
  * Streams.  With the default option hybrid_sync = 1 a *_dev call that runs
  * generated ("scheduled") kernels WAITS on its stream once per stage of the
