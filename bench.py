@@ -221,6 +221,9 @@ def main():
     ap.add_argument("--gen-opts", default="",
                     help="re-generate the circuit's kernels with these generator options (engine option jit_gen_opts, "
                          "e.g. near_band=0) before the run: A/B measurements of generator choices")
+    ap.add_argument("--overlap-gather", action="store_true",
+                    help="copy every step's probe voltages to pinned host memory on a second stream while the next step "
+                         "runs (with --async the host never waits inside a step: launch k+1 is enqueued under copy k)")
     ap.add_argument("--async", dest="async_calls", action="store_true",
                     help="engine option hybrid_sync=0: the transient calls only enqueue, the host never waits inside them")
     ap.add_argument("--large-batch", type=int, default=65536,
@@ -308,11 +311,25 @@ def main():
 
     it_before = iters.clone()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    copy_stream = torch.cuda.Stream() if args.overlap_gather else None
+    probe_rows = nl.probes if nl.probes else [0]
+    host_probe = [torch.empty((len(probe_rows), B), dtype=torch.float64).pin_memory() for _ in range(args.steps)] \
+        if args.overlap_gather else []
+    staged = [torch.empty((len(probe_rows), B), dtype=torch.float64, device=dev) for _ in range(2)] if args.overlap_gather else []
     t_start = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
         eng.tran(params, x, tstep, step_idx, S, iters, status)
         ev[k][1].record()
+        if copy_stream is not None:
+            # step k's probe voltages: snapshot on the compute stream (x is overwritten by step k+1), D2H on the copy
+            # stream under step k+1
+            if k >= 2:
+                torch.cuda.current_stream().wait_stream(copy_stream)      # the snapshot buffer is free again
+            staged[k & 1].copy_(x[probe_rows, :])
+            copy_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(copy_stream):
+                host_probe[k].copy_(staged[k & 1], non_blocking=True)
         step_idx += S
     torch.cuda.synchronize()
     shard.barrier()
@@ -438,6 +455,7 @@ def main():
             },
             "dist_backend": shard.backend_name(),
             "hybrid_sync": 0 if args.async_calls else 1,
+            "overlap_gather": bool(args.overlap_gather),
             "near_threshold": {"verified": eng.stat("near_verified"), "rolled_back": eng.stat("near_rolled_back")},
             "netlist_bcast_ms": bcast_ms,
             "result_gather_ms": gather_ms,
