@@ -1121,9 +1121,10 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
         // (the squares are accumulated with fma: like the order of this sum, that touches the threshold's last bits only)
         o << "            { const double xn = x" << s << " + al * (w" << s << " - x" << s << "); const double d = xn - x" << s << "; ss = fma(d, d, ss); x" << s << " = xn; }\n";
     o << "            ss = grp_sum16(ss);\n"
-      << "            const double err = sqrt(ss);\n"
       << "            const bool good = active && (ss < 1.0e300);      // else: a non-finite solve, the general kernel classifies it\n"
-      << "            const bool conv = err < " << lit(K.tran_tol) << ";\n"
+      << "            // decided on the squared norm (sqrt is monotonic: `ss < tol^2` and `sqrt(ss) < tol` can differ only within\n"
+      << "            // an ulp or two of the threshold -- the same last bits the order of the sum above already touches)\n"
+      << "            const bool conv = ss < " << lit(K.tran_tol * K.tran_tol) << ";\n"
       << "            viol = viol || (active && !good);\n"
       << "            it += good ? 1 : 0;\n"
       << "            if (good && !conv && iter == " << (K.tran_max_iters - 1) << ") st |= ST_TRAN_NONCONV;   // tanalisis.cpp:372-376 (kept, as upstream)\n"

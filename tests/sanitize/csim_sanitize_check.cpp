@@ -1,7 +1,8 @@
 // csim_sanitize_check -- CPU-side code under AddressSanitizer + UndefinedBehaviorSanitizer (GPU ASan is not
 // available on this pool): the front-end (parser, circuit, flatten), the assembly plan, all three kernel generators
 // with the shipped schedules, the sixteen-lane plan's host interpreter, and the CPU oracle (DC + a few transient
-// steps, the threaded batch driver).  Built by `make sanitize`, run by tests/test_sanitizers.py.
+// steps, the threaded batch driver).  Test infrastructure (it links the oracle): built by tests/sanitize/Makefile, run by
+// tests/test_sanitizers.py.
 //
 //   csim_sanitize_check <netlist.sp> <schedule-file|->
 #include <cstdio>
@@ -11,11 +12,11 @@
 #include <string>
 #include <vector>
 
-#include "../api/circuit.hpp"
-#include "../api/parser.hpp"
-#include "../engine/codegen.hpp"
-#include "../engine/group_plan.hpp"
-#include "../engine/plan.hpp"
+#include "api/circuit.hpp"
+#include "api/parser.hpp"
+#include "engine/codegen.hpp"
+#include "engine/group_plan.hpp"
+#include "engine/plan.hpp"
 
 extern "C" {
 #include "mna_oracle.h"

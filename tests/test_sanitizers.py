@@ -1,6 +1,6 @@
 """CPU-side code under AddressSanitizer + UndefinedBehaviorSanitizer (GPU ASan is not available on this
 pool): front-end, assembly plan, the three kernel generators with the shipped schedules, the sixteen-lane plan's host
-interpreter, and the CPU oracle including its threaded batch driver (csrc/tools/csim_sanitize_check.cpp)."""
+interpreter, and the CPU oracle including its threaded batch driver (tests/sanitize/)."""
 import os
 import subprocess
 
@@ -13,9 +13,10 @@ CSRC = os.path.join(ROOT, "circuitsimulator_amd", "csrc")
 
 @pytest.fixture(scope="module")
 def checker():
-    p = subprocess.run(["make", "-s", "-C", CSRC, "sanitize"], capture_output=True, text=True, timeout=900)
+    here = os.path.join(ROOT, "tests", "sanitize")
+    p = subprocess.run(["make", "-s", "-C", here], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
-    return os.path.join(CSRC, "build", "csim_sanitize_check")
+    return os.path.join(here, "_build", "csim_sanitize_check")
 
 
 @pytest.mark.parametrize("name", ["buffer", "dbmixer"])
