@@ -1002,7 +1002,7 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
       << "extern \"C\" __global__ void __launch_bounds__(64)\n"
       << "csim_lin16_factor_kernel(const double* __restrict__ params, int B, double dt, long long nSteps, int outStride,\n"
       << "                         const int* __restrict__ done, unsigned char* __restrict__ fallback, double* __restrict__ work)\n{\n"
-      << "    const int b = blockIdx.x * 64 + threadIdx.x;\n"
+      << "    const int b = blockIdx.x * blockDim.x + threadIdx.x;     // blocks of 16, 32 or 64 lanes (see the launcher)\n"
       << "    const bool inb = b < B;\n"
       << "    const long long bb = inb ? b : B - 1;\n"
       << "    const long long SB = B, SBW = ((long long)B + 63) / 64 * 64;     // the tape's instance stride: whole wavefronts\n"
