@@ -986,15 +986,24 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
     std::vector<int32_t> kind(ir.kind, ir.kind + ir.n_elems), slot(ir.param_slot, ir.param_slot + ir.n_elems),
         wave(ir.wave, ir.wave + ir.n_elems), waveN(ir.wave_n, ir.wave_n + ir.n_elems);
 
-    const int oXP = 0, oTS = oXP + NP + 1;
-    int instDoubles = oTS + 2 * (nStep + 2);
+    // the sources' parameters are copied to LDS once per launch (a global load per parameter and time step put ~2 000
+    // cycles of s_waitcnt into every step): PS[srcOff[n] + i] = parameter i of the n-th source element
+    std::vector<int32_t> srcOff(srcTab.size(), 0);
+    int nSrcParams = 0;
+    for (std::size_t i = 0; i < srcElems.size(); ++i) {
+        const int e = srcElems[i];
+        srcOff[i] = nSrcParams;
+        nSrcParams += (e + 1 < ir.n_elems ? ir.param_slot[e + 1] : ir.n_params) - ir.param_slot[e];
+    }
+    const int oXP = 0, oTS = oXP + NP + 1, oPS = oTS + 2 * (nStep + 2);
+    int instDoubles = oPS + std::max(nSrcParams, 1);
     if (instDoubles * 8 * 4 > 40 * 1024) return std::string();           // four workgroups per CU (one wave per SIMD)
 
     std::ostringstream o;
     o << "// ---- linear circuit, sixteen lanes per instance: tape, iterate and x_raw in registers (codegen_linear.cpp)\n"
       << linearPrelude()
       << intArray("l16_slot", slot) << intArray("l16_wave", wave) << intArray("l16_waveN", waveN)
-      << intArray("l16_src", srcTab) << intArray("l16_srcOut", srcOut)
+      << intArray("l16_src", srcTab) << intArray("l16_srcOut", srcOut) << intArray("l16_srcOff", srcOff)
       << intArray("l16_hA", hA) << intArray("l16_hB", hB) << intArray("l16_hOut", hOut) << intArray("l16_rhs", rhsIdx)
       << "// pivot schedule: " << (sc.str().empty() ? std::string("-") : sc.str()) << "\n"
       << "// factorisation, once per launch, one LANE per instance; writes the tape [entry][lane of the consumer][instance]\n"
@@ -1039,6 +1048,7 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
       << "    if (!__any(inb && done[bb] < nSteps)) return;\n"
       << "    double* const XP = lds + q * " << instDoubles << " + " << oXP << ";   // state at the start of the step (history, checkpoint, probes); XP[" << NP << "] = 0\n"
       << "    double* const TS = lds + q * " << instDoubles << " + " << oTS << ";   // per-step terms with sign: TS[2t] = +v, TS[2t+1] = -v; slot " << zeroSlot << " = 0\n"
+      << "    double* const PS = lds + q * " << instDoubles << " + " << oPS << ";   // the source elements' parameters\n"
       << "    auto P = [&](int slot) -> double { return params[(long long)slot * SB + bb]; };\n";
     for (int t = 0; t < G; ++t) o << "    const double mk" << t << " = (g == " << t << ") ? 1.0 : 0.0;\n";
     o << "    // the tape: this lane's operands in its order of use\n";
@@ -1051,7 +1061,7 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
     for (int r = 0; r < srcRounds; ++r)
         o << "    const int se" << r << " = l16_src[" << r * G << " + g];       // source evaluated by this lane in round " << r << " (-1: none)\n"
           << "    const int sq" << r << " = se" << r << " >= 0 ? se" << r << " : 0;\n"
-          << "    const int ssl" << r << " = l16_slot[sq" << r << "], sto" << r << " = l16_srcOut[" << r * G << " + g], swv" << r << " = l16_wave[sq" << r
+          << "    const int ssl" << r << " = l16_slot[sq" << r << "], spo" << r << " = l16_srcOff[" << r * G << " + g], sto" << r << " = l16_srcOut[" << r * G << " + g], swv" << r << " = l16_wave[sq" << r
           << "], swn" << r << " = l16_waveN[sq" << r << "];\n";
     for (int r = 0; r < histRounds; ++r)
         o << "    const int ha" << r << " = l16_hA[" << r * G << " + g], hb" << r << " = l16_hB[" << r * G << " + g], ho" << r << " = l16_hOut[" << r * G << " + g];\n";
@@ -1060,6 +1070,11 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
         for (int s = 0; s < S; ++s)
             for (int t = 0; t < rhsMax[sz(s)]; ++t, ++base) o << "    const int ri" << s << "_" << t << " = l16_rhs[" << base * G << " + g];\n";
     }
+    for (int r = 0; r < srcRounds; ++r)
+        o << "    if (se" << r << " >= 0) {\n"
+          << "        const int np = (se" << r << " + 1 < " << ir.n_elems << " ? l16_slot[se" << r << " + 1] : " << ir.n_params << ") - ssl" << r << ";\n"
+          << "        for (int i = 0; i < np; ++i) PS[spo" << r << " + i] = P(ssl" << r << " + i);\n"
+          << "    }\n";
     o << "    for (int i = g; i < " << 2 * (nStep + 2) << "; i += 16) TS[i] = 0.0;\n"
       << "    if (g == 0) XP[" << NP << "] = 0.0;\n";
     for (int s = 0; s < S; ++s)
@@ -1090,7 +1105,7 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
         o << "        const double hp" << r << " = XP[ha" << r << "], hq" << r << " = XP[hb" << r << "];\n";
     for (int r = 0; r < srcRounds; ++r)
         o << "        {\n"
-          << "            const double v = se" << r << " >= 0 ? grp_source_tran([&](int i) { return P(ssl" << r << " + i); }, swv" << r << ", swn" << r << ", tNow, " << lit(K.pi) << ") : 0.0;\n"
+          << "            const double v = se" << r << " >= 0 ? grp_source_tran([&](int i) { return PS[spo" << r << " + i]; }, swv" << r << ", swn" << r << ", tNow, " << lit(K.pi) << ") : 0.0;\n"
           << "            TS[2 * sto" << r << "] = v; TS[2 * sto" << r << " + 1] = -v;\n"
           << "        }\n";
     for (int r = 0; r < histRounds; ++r)
