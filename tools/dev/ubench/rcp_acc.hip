@@ -37,6 +37,17 @@ int main()
         ec = std::fmax(ec, (double)fabsl(((long double)c[i] - t) / t));
         ne2 += b[i] != exact; nec += c[i] != exact; ndiff += b[i] != c[i];
     }
+    // special operands through the cubic-step reciprocal the generated kernels use (rcp_nr / grp_rcp_nr): what a pivot of
+    // that kind turns into, against the true quotient 1 / a
+    {
+        const double sp[12] = {INFINITY, -INFINITY, 0.0, -0.0, 4.9406564584124654e-324, 2.2250738585072014e-308, -2.2250738585072014e-308,
+                               1e-310, 1.7976931348623157e308, 8.98846567431158e307, 1e-300, NAN};
+        hipMemcpy(dx, sp, sizeof sp, hipMemcpyHostToDevice);
+        k<<<1, 64>>>(dx, da, db, dc, 12);
+        double out[12];
+        hipMemcpy(out, dc, sizeof out, hipMemcpyDeviceToHost);
+        for (int i = 0; i < 12; ++i) printf("  rcp_nr(%-24.17g) = %-24.17g   1/a = %.17g\n", sp[i], out[i], 1.0 / sp[i]);
+    }
     printf("max rel err: v_rcp_f64 %.3g (2^%.1f), two quadratic steps %.3g, one cubic step %.3g; not correctly rounded: %ld / %ld of %d; quadratic != cubic in %ld\n",
            e0, std::log2(e0), e2, ec, ne2, nec, n, ndiff);
     return 0;
