@@ -269,10 +269,11 @@ def main():
         eng.set_option("lanes_per_instance", args.lanes)
     if args.async_calls:
         eng.set_option("hybrid_sync", 0)
-    if args.gen_opts and eng.tran_kernel != "general":
-        sched, dc_sched = eng.loaded_schedules()
-        eng.set_option("jit_gen_opts", args.gen_opts)
-        eng.jit_with_schedules(sched, dc_sched)
+    if args.gen_opts:
+        eng.set_option("jit_gen_opts", args.gen_opts)          # also what a later JIT of a netlist without a shipped library uses
+        if eng.tran_kernel != "general":
+            sched, dc_sched = eng.loaded_schedules()
+            eng.jit_with_schedules(sched, dc_sched)
     N, B, S = nl.n_unknowns, args.batch, args.tsteps
     tstep = nl.tstep
 

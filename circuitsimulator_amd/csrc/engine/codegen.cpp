@@ -119,6 +119,8 @@ bool GeneratorOptions::set(const std::string& keyval)
     if (key == "near_band_dc") { nearBandDc = std::max(0.0, std::atof(val.c_str())); return true; }
     if (key == "near_form") { nearForm = std::atoi(val.c_str()) != 0 ? 1 : 0; return true; }
     if (key == "lds_pad") { ldsPad = std::atoi(val.c_str()) != 0 ? 1 : 0; return true; }
+    if (key == "lin_factor_block") { linFactorBlock = std::atoi(val.c_str()); return linFactorBlock == 0 || linFactorBlock == 16 || linFactorBlock == 32 || linFactorBlock == 64; }
+    if (key == "lin_src_lds") { linSrcLds = std::atoi(val.c_str()) != 0 ? 1 : 0; return true; }
     if (key == "sweep") {
         sweep.clear();
         std::size_t i = 0;
@@ -142,6 +144,8 @@ uint64_t scheduleHash(const csim_ir& ir, const ScheduleSet& set, const Generator
     { uint64_t bits; std::memcpy(&bits, &gopt.nearBandDc, sizeof bits); mix(bits ^ 0x165667B19E3779F9ull); }
     mix(static_cast<uint64_t>(gopt.nearForm + 3) * 0x27D4EB2F165667C5ull);
     mix(static_cast<uint64_t>(gopt.ldsPad + 5) * 0x9E3779B185EBCA87ull);
+    mix(static_cast<uint64_t>(gopt.linFactorBlock + 13) * 0xC2B2AE3D27D4EB4Full);
+    mix(static_cast<uint64_t>(gopt.linSrcLds + 17) * 0x165667B19E3779F9ull);
     for (std::size_t a = 1; a < set.alts.size(); ++a) {
         h ^= 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
         for (int p : set.alts[a].pivotPos) { h ^= static_cast<uint64_t>(p + 1); h *= 1099511628211ull; }
@@ -1051,7 +1055,7 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     // Linear circuits first try the sixteen-lanes-per-instance form (tape, iterate and x_raw in registers); circuits
     // whose tape does not fit the register file get the lane-per-instance form (iterate in LDS, tape streamed).
     int linWork = 0, linLanes = 0;
-    const std::string lin16Src = emitLinearGroupKernel(ir, ap, set.alts[0], &linWork);
+    const std::string lin16Src = emitLinearGroupKernel(ir, ap, set.alts[0], &linWork, gopt);
     const bool haveLinear16 = !lin16Src.empty();
     const std::string linSrc = haveLinear16 ? std::string() : emitLinearKernel(ir, ap, set.alts[0], &linWork, &linLanes);
     const bool haveLinear = haveLinear16 || !linSrc.empty();
@@ -1211,7 +1215,7 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         src << "    if (work) {   // linear circuit: factor once per launch (lane per instance), then the time steps (16 lanes per instance)\n"
             << "        // the factorisation is one long dependent chain per lane (latency-bound): small batches run it with 16 or 32\n"
             << "        // lanes per wave so that more SIMDs take part (8192 instances: 512 waves instead of 128)\n"
-            << "        const unsigned fl = B <= 16384 ? 16u : (B <= 32768 ? 32u : 64u);\n"
+            << "        const unsigned fl = " << (gopt.linFactorBlock ? std::to_string(gopt.linFactorBlock) + "u" : std::string("B <= 16384 ? 16u : (B <= 32768 ? 32u : 64u)")) << ";\n"
             << "        hipLaunchKernelGGL(csim_lin16_factor_kernel, dim3(((unsigned)B + fl - 1) / fl), dim3(fl), 0, (hipStream_t)stream,\n"
             << "                           params, B, dt, nSteps, outStride, aux->done, aux->fallback, work);\n"
             << "        hipLaunchKernelGGL(csim_tran_linear16_kernel, dim3((unsigned)((B + 3) / 4)), dim3(64), 0, (hipStream_t)stream,\n"

@@ -84,13 +84,15 @@ struct GeneratorOptions {
                                  // (measured, profiles/r03_group16_b4096_*: SQ_LDS_BANK_CONFLICT 30.9 % of the LDS-active cycles
                                  // either way -- the conflicts come from the per-lane gathers / scatters of the MOSFET pass, not
                                  // from the [row][16] reads -- and 0.8 % slower padded)
+    int linFactorBlock = 0;      // linear sixteen-lane library: lanes per workgroup of the factor kernel (0 = 16 / 32 / 64 by batch size)
+    int linSrcLds = 1;           // linear sixteen-lane kernel: 1 = the sources' parameters are copied to LDS once per launch
     int nearForm = 0;            // sixteen-lane kernel, how a pass records a near tie: 0 = running minimum of |err - tol| (two
                                  // VALU instructions, one loop-carried double), 1 = two more compares into a loop-carried lane mask
     bool set(const std::string& keyval);      // "barrier_every=3", "sweep=0,16,32", "stage_ahead=3", "pipeline_mos=0", "group_waves=2", "near_band=2e-8", "near_band_dc=1e-5"
 };
 
 // bumped whenever the emitted code or the launcher ABI of a generated library changes
-constexpr int kGeneratorRevision = 30;
+constexpr int kGeneratorRevision = 31;
 
 // identifies (topology, constants, schedule); names the generated library
 uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch);
@@ -109,7 +111,8 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
 // codegen_linear.cpp: the same for SIXTEEN lanes per instance with iterate, x_raw and the factor tape in registers
 // (kernels csim_lin16_factor_kernel + csim_tran_linear16_kernel; needs groupPreludeSource() in front); "" when the
 // circuit has MOSFETs or its tape does not fit the register file.  workDoubles: doubles per instance of the tape.
-std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sc, int* workDoubles);
+std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sc, int* workDoubles,
+                                  const GeneratorOptions& gopt = GeneratorOptions());
 
 // complete .hip translation unit: kernel + extern "C" launcher + metadata
 std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, const ScheduleSet& set,

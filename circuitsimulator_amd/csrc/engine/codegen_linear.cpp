@@ -767,7 +767,8 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
 // work -- are elementwise on registers, all lanes busy.  The factorisation runs once per launch in its own
 // lane-per-instance kernel (csim_lin16_factor_kernel, the straight-line block of buildLinearFactor) and
 // writes the tape to global memory in consumer order: [entry r][lane g][instance], read once per launch.
-std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sc, int* workDoubles)
+std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sc, int* workDoubles,
+                                  const GeneratorOptions& gopt)
 {
     const int N = ir.n_unknowns, G = 16;
     const csim_consts& K = ir.k;
@@ -1105,7 +1106,7 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
         o << "        const double hp" << r << " = XP[ha" << r << "], hq" << r << " = XP[hb" << r << "];\n";
     for (int r = 0; r < srcRounds; ++r)
         o << "        {\n"
-          << "            const double v = se" << r << " >= 0 ? grp_source_tran([&](int i) { return PS[spo" << r << " + i]; }, swv" << r << ", swn" << r << ", tNow, " << lit(K.pi) << ") : 0.0;\n"
+          << "            const double v = se" << r << " >= 0 ? grp_source_tran([&](int i) { return " << (gopt.linSrcLds ? "PS[spo" + std::to_string(r) + " + i]" : "P(ssl" + std::to_string(r) + " + i)") << "; }, swv" << r << ", swn" << r << ", tNow, " << lit(K.pi) << ") : 0.0;\n"
           << "            TS[2 * sto" << r << "] = v; TS[2 * sto" << r << " + 1] = -v;\n"
           << "        }\n";
     for (int r = 0; r < histRounds; ++r)

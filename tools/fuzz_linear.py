@@ -31,7 +31,7 @@ def main():
     bad = refused = n16 = 0
     for seed in range(a.first, a.first + a.count):
         rs = np.random.RandomState(seed)
-        nl = Netlist.from_text(t._random_netlist(rs, rs.randint(3, 60), 0))
+        nl = Netlist.from_text(t._random_netlist(rs, rs.randint(3, 40), 0))
         eng = Engine(nl, 0)
         B, steps = 37, 60
         params = eng.mc_params(seed, 0.05, 0, B)
@@ -54,6 +54,7 @@ def main():
             problems.append("status")
         if not np.array_equal(fast["x"][:, clean], slow["x"][:, clean]):
             problems.append("x differs by up to %.2e" % np.abs(fast["x"][:, clean] - slow["x"][:, clean]).max())
+        print("seed %d N=%d lanes=%d %s" % (seed, nl.n_unknowns, eng.lanes_for_batch(B), "ok" if not problems else "MISMATCH"), flush=True)
         if problems:
             bad += 1
             print("seed %d N=%d (%d clean of %d): %s" % (seed, nl.n_unknowns, int(clean.sum()), B, "; ".join(problems)), flush=True)
