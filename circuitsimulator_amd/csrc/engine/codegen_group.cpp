@@ -202,7 +202,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     // (codegen.hpp), so off by default.
     int instDoubles = oST + (nStage + 1) * G;
     while (gopt.ldsPad && instDoubles % 32 != 16) ++instDoubles;
-    if (instDoubles * 8 * 4 > 64 * 1024) return std::string();  // keep 2+ waves per CU possible; larger circuits: no group kernel
+    if (instDoubles * 8 * 4 > 150 * 1024) return std::string();  // one CU's LDS (a workgroup of four instances must fit)
 
     std::ostringstream o;      // (the shared device code, groupPreludeSource(), is emitted by the caller)
 

@@ -293,6 +293,34 @@ def test_group_kernel_three_slots_and_two_mosfet_rounds(torch_mod, tmp_path, mon
     assert res[16]["iters"][7] == o["iters"] and rel_err(res[16]["x"][:, 7], o["x_final"]).max() < TOL
 
 
+def test_group_kernel_four_slots_55_unknowns(torch_mod, tmp_path, monkeypatch):
+    """49 <= N <= 64: four rows per lane.  A 55-unknown amplifier line (25 MOSFETs: two evaluation rounds) through the
+    sixteen-lanes-per-instance kernel -- until round 3 such circuits had the wave-per-instance LDS kernel only -- against the
+    general kernel (per-step NR counts, status, states) and the oracle."""
+    from circuitsimulator_amd import Engine, Netlist
+    monkeypatch.setenv("CSIM_JIT_DIR", str(tmp_path / "jit"))
+    nl = Netlist.from_text(_amplifier_line(25))
+    assert nl.n_unknowns == 55
+    eng = Engine(nl, 0)
+    B, steps = 24, 200
+    params = eng.mc_params(5, 0.03, 0, B)
+    slow = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+    eng.jit_scheduled(params, plan_steps=steps)
+    assert eng.tran_kernel == "scheduled" and "group16" in eng.sched_info["text"]
+    eng.set_option("lanes_per_instance", 16)
+    import time
+    t0 = time.perf_counter()
+    fast = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+    dt = time.perf_counter() - t0
+    print("55 unknowns, 16 lanes per instance: %d instances x %d steps in %.3f s" % (B, steps, dt))
+    assert np.array_equal(fast["step_iters"], slow["step_iters"])
+    assert np.array_equal(fast["status"] & NOFB, slow["status"])
+    assert rel_err(fast["x"].T, slow["x"].T).max() < TOL
+    assert ((fast["status"] & (FALLBACK | FAITHFUL)) == 0).sum() > B // 2        # the group kernel itself did the work
+    o = _orc().tran(nl.ir_ptr, nl.n_unknowns, params.cpu().numpy(), 3, nl.tstep, nl.tstep * steps, want_rows=False)
+    assert fast["iters"][3] == o["iters"] and rel_err(fast["x"][:, 3], o["x_final"]).max() < TOL
+
+
 def test_group_kernel_carries_every_recorded_schedule(engines, torch_mod):
     """buffer.sp at its shipped step alternates between ten pivot schedules.  The group kernel has one
     solve body per schedule, all over the first schedule's row placement (pivot rows at arbitrary lanes,
