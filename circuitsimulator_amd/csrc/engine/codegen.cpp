@@ -1213,8 +1213,7 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     src << "    (void)work;\n";
     if (haveLinear16)
         src << "    if (work) {   // linear circuit: factor once per launch (lane per instance), then the time steps (16 lanes per instance)\n"
-            << "        // the factorisation is one long dependent chain per lane (latency-bound): small batches run it with 16 or 32\n"
-            << "        // lanes per wave so that more SIMDs take part (8192 instances: 512 waves instead of 128)\n"
+            << "        // (lanes per workgroup of the factorisation: generator option lin_factor_block)\n"
             << "        const unsigned fl = " << (gopt.linFactorBlock ? std::to_string(gopt.linFactorBlock) + "u" : std::string("B <= 16384 ? 16u : (B <= 32768 ? 32u : 64u)")) << ";\n"
             << "        hipLaunchKernelGGL(csim_lin16_factor_kernel, dim3(((unsigned)B + fl - 1) / fl), dim3(fl), 0, (hipStream_t)stream,\n"
             << "                           params, B, dt, nSteps, outStride, aux->done, aux->fallback, work);\n"

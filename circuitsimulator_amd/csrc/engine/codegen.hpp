@@ -84,7 +84,8 @@ struct GeneratorOptions {
                                  // (measured, profiles/r03_group16_b4096_*: SQ_LDS_BANK_CONFLICT 30.9 % of the LDS-active cycles
                                  // either way -- the conflicts come from the per-lane gathers / scatters of the MOSFET pass, not
                                  // from the [row][16] reads -- and 0.8 % slower padded)
-    int linFactorBlock = 0;      // linear sixteen-lane library: lanes per workgroup of the factor kernel (0 = 16 / 32 / 64 by batch size)
+    int linFactorBlock = 64;     // linear sixteen-lane library: lanes per workgroup of the factor kernel (0 = 16 / 32 / 64 by batch size;
+                                 // measured on the N = 257 ladder at B = 8192, same box: 64 -> 3.09 ms per launch, by batch size (16) -> 3.16 ms)
     int linSrcLds = 1;           // linear sixteen-lane kernel: 1 = the sources' parameters are copied to LDS once per launch
     int nearForm = 0;            // sixteen-lane kernel, how a pass records a near tie: 0 = running minimum of |err - tol| (two
                                  // VALU instructions, one loop-carried double), 1 = two more compares into a loop-carried lane mask
@@ -92,7 +93,7 @@ struct GeneratorOptions {
 };
 
 // bumped whenever the emitted code or the launcher ABI of a generated library changes
-constexpr int kGeneratorRevision = 32;
+constexpr int kGeneratorRevision = 33;
 
 // identifies (topology, constants, schedule); names the generated library
 uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch);
