@@ -1066,6 +1066,12 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     const bool haveGroup = !groupSrc.empty();
     if (haveLinear16 || haveGroup) src << groupPreludeSource(ir);
     src << lin16Src << linSrc;
+    // DC operating point of a linear circuit on its recorded DC pivot sequence (one direct solve)
+    int linDcWork = 0;
+    const std::string linDcSrc = (haveLinear && !set.dcAlts.empty()) ? emitLinearDcKernel(ir, ap, set.dcAlts[0], &linDcWork) : std::string();
+    const bool haveLinearDc = !linDcSrc.empty();
+    src << linDcSrc;
+    if (linDcWork > linWork) linWork = linDcWork;               // one work area serves both
 
     const int leanBudget = 80 - N;
     // a variant is emitted only if its LDS image fits one CU (163 840 B)
@@ -1167,20 +1173,26 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     src << "};\n    *nAlts = " << set.alts.size() << ";\n    *n = " << N << ";\n    return table;\n}\n"
         << "// DC operating point: recorded alternatives and launcher (n_alts == 0: no DC kernel in this library)\n"
         << "extern \"C\" const int* csim_sched_dc_alts(int* nAlts, int* n)\n{\n    static const int table[] = {";
-    if (haveDc) {
-        for (std::size_t a = 0; a < set.dcAlts.size(); ++a)
+    if (haveDc || haveLinearDc) {
+        for (std::size_t a = 0; a < (haveDc ? set.dcAlts.size() : 1); ++a)
             for (int k = 0; k < N; ++k) src << (a + k ? ", " : "") << set.dcAlts[a].pivotPos[static_cast<std::size_t>(k)];
     } else {
         src << "0";
     }
-    src << "};\n    *nAlts = " << (haveDc ? set.dcAlts.size() : 0) << ";\n    *n = " << N << ";\n    return table;\n}\n"
+    src << "};\n    *nAlts = " << (haveDc ? set.dcAlts.size() : (haveLinearDc ? 1 : 0)) << ";\n    *n = " << N << ";\n    return table;\n}\n"
         << "// variant 0 = the faithful kernel, 2 = the fast one; only (or null) = mask of the instances to run;\n"
         << "// an instance the kernel cannot finish (pivot check, non-finite solve, guarded decision) gets fallback[b] = 1\n"
         << "extern \"C\" int csim_sched_dc_launch(const double* params, int B, double* xout, int* iters, unsigned* status,\n"
         << "                                    unsigned char* fallback, int* violFlag, const unsigned char* only,\n"
-        << "                                    void* stream, int variant)\n{\n";
-    if (haveDc)
-        src << "    if (B <= 0) return 0;\n"
+        << "                                    double* work, void* stream, int variant)\n{\n";
+    if (haveLinearDc)
+        src << "    if (B <= 0) return 0;\n    (void)variant;\n"
+            << "    if (!work) return (int)hipErrorInvalidValue;     // the linear-circuit kernels need their work area\n"
+            << "    hipLaunchKernelGGL(csim_dc_linear_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream,\n"
+            << "                       params, B, xout, iters, status, fallback, violFlag, only, work);\n"
+            << "    return (int)hipGetLastError();\n}\n";
+    else if (haveDc)
+        src << "    if (B <= 0) return 0;\n    (void)work;\n"
             << "    if (variant == 2)\n"
             << "        hipLaunchKernelGGL(csim_dc_sched_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream,\n"
             << "                           params, B, xout, iters, status, fallback, violFlag, only);\n"
@@ -1189,7 +1201,7 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
             << "                           params, B, xout, iters, status, fallback, violFlag, only);\n"
             << "    return (int)hipGetLastError();\n}\n";
     else
-        src << "    (void)params; (void)B; (void)xout; (void)iters; (void)status; (void)fallback; (void)violFlag; (void)only; (void)stream; (void)variant;\n    return -1;\n}\n";
+        src << "    (void)params; (void)B; (void)xout; (void)iters; (void)status; (void)fallback; (void)violFlag; (void)only; (void)work; (void)stream; (void)variant;\n    return -1;\n}\n";
     src << "// variant: 0/1 = lean (measured fastest at every batch size: park-budget sweep in DESIGN.md),\n"
         << "//          2 = rich (tuning aid), 10+k = sweep kernels when generated with CSIM_CG_SWEEP\n"
         << "// auxiliaries of the hand-over protocol (device pointers; engine_internal.hpp holds the same struct):\n"

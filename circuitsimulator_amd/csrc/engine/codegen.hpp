@@ -93,7 +93,7 @@ struct GeneratorOptions {
 };
 
 // bumped whenever the emitted code or the launcher ABI of a generated library changes
-constexpr int kGeneratorRevision = 33;
+constexpr int kGeneratorRevision = 34;
 
 // identifies (topology, constants, schedule); names the generated library
 uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch);
@@ -114,6 +114,10 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
 // circuit has MOSFETs or its tape does not fit the register file.  workDoubles: doubles per instance of the tape.
 std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sc, int* workDoubles,
                                   const GeneratorOptions& gopt = GeneratorOptions());
+
+// codegen_linear.cpp: DC operating point of a linear circuit (one direct solve, lane per instance, the reference's
+// arithmetic) on the recorded DC pivot schedule; workDoubles: doubles per instance of its tape
+std::string emitLinearDcKernel(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& dcSchedule, int* workDoubles);
 
 // complete .hip translation unit: kernel + extern "C" launcher + metadata
 std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, const ScheduleSet& set,

@@ -245,12 +245,13 @@ struct LinearFactor {
     std::vector<int> coefHandle;                // per element: handle of C/dt (capacitor) or L/dt (inductor), else -1
 };
 
-void buildLinearFactor(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sc, LinearFactor& F)
+// dcMode: the system of dcSolveDirectLU (src/dcanalysis.cpp:46-68): capacitors open, inductors 0 V sources, no gmin.
+void buildLinearFactor(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sc, LinearFactor& F, bool dcMode = false)
 {
     const int N = ir.n_unknowns;
     const csim_consts& K = ir.k;
     const int LD = ap.LD;
-    const GatherPlan& gpl = ap.tran;
+    const GatherPlan& gpl = dcMode ? ap.dc : ap.tran;
     int& nHandles = F.nHandles;
     auto rd = rdHandle;
     auto st = [](int h) { return "@S" + std::to_string(h) + "@"; };
@@ -264,7 +265,7 @@ void buildLinearFactor(const csim_ir& ir, const AssemblyPlan& ap, const PivotSch
     std::ostringstream consts;                            // code that fills the launch constants
     int nConstStmts = 0;                                  // a scheduling barrier every 16: see the factor block
     termF[static_cast<std::size_t>(ap.termOne)] = LV::konst(1.0);
-    termF[static_cast<std::size_t>(ap.termGmin)] = LV::konst(K.tran_gmin);
+    termF[static_cast<std::size_t>(ap.termGmin)] = dcMode ? LV() : LV::konst(K.tran_gmin);      // the direct DC solve stamps no gmin
     auto PX = [](int slot) { return "params[" + std::to_string(slot) + "LL * SB + bb]"; };
     // the same parameter as read by the factor block: through an always-zero offset the compiler cannot fold, so that
     // it does not keep all C/dt of the tape-filling block alive (in scratch) for the factor block's matrix entries
@@ -277,6 +278,7 @@ void buildLinearFactor(const csim_ir& ir, const AssemblyPlan& ap, const PivotSch
                 termF[static_cast<std::size_t>(tb + T_R_G)] = LV::dyn("lin_ginv(" + PF(s) + ")");
                 break;
             case CSIM_C: {
+                if (dcMode) break;                                          // open at DC
                 const int h = nHandles++;
                 F.coefHandle[static_cast<std::size_t>(e)] = h;
                 consts << "    { const double pk = lin_gc(" << PX(s) << ", dt); " << st(h) << " }\n";
@@ -285,6 +287,7 @@ void buildLinearFactor(const csim_ir& ir, const AssemblyPlan& ap, const PivotSch
                 break;
             }
             case CSIM_L: {
+                if (dcMode) break;                                          // a 0 V source at DC: the plan's exact +-1 incidence only
                 const int h = nHandles++;
                 F.coefHandle[static_cast<std::size_t>(e)] = h;
                 consts << "    { const double L = " << PX(s) << "; viol = viol || !(L > 0.0); const double pk = L / dt; " << st(h) << " }\n";
@@ -741,6 +744,149 @@ std::string emitLinearKernel(const csim_ir& ir, const AssemblyPlan& ap, const Pi
       << "}\n#pragma clang fp contract(fast)\n\n";
     if (workDoubles) *workDoubles = nTape;
     if (lanesPerWave) *lanesPerWave = LPW;
+    return o.str();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// DC operating point of a linear circuit: dcSolveDirectLU (src/dcanalysis.cpp:46-68) -- ONE solve of the system stamped
+// at x = 0 with full sources, capacitors open, inductors as 0 V sources, no gmin.  One lane per instance, straight-line:
+// the factor block of buildLinearFactor on the DC plan with the recorded DC pivots (every choice verified), its values
+// parked on the tape, then one forward / back substitution that reads them back.  The reference's arithmetic (true
+// divisions, no contraction, sums in stamping order): bit for bit the general kernel's operating point.  A failed pivot
+// check (the reference would have swapped differently, or returned the zero vector) leaves the instance to the general
+// kernel.  Without this kernel the operating points of the configs[3] ladder cost more than its whole transient
+// (11 ms against 3 ms for 8192 instances: the wave-per-instance large-N kernel).
+std::string emitLinearDcKernel(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sc, int* workDoubles)
+{
+    const int N = ir.n_unknowns;
+    if (ir.has_nonlinear || N <= 0) return std::string();
+    const GatherPlan& gpl = ap.dc;
+    LinearFactor F;
+    buildLinearFactor(ir, ap, sc, F, true);
+    // right-hand side: source values at DC, SourceSpec::evalDC(1.0) = (dc + (SIN ? v0 : 0)) * 1.0 (include/sim.hpp:152-158)
+    std::vector<LV> termS(static_cast<std::size_t>(ap.nTerms));
+    termS[static_cast<std::size_t>(ap.termOne)] = LV::konst(1.0);
+    std::ostringstream srcCode;
+    for (int e = 0; e < ir.n_elems; ++e) {
+        if (ir.kind[e] != CSIM_V && ir.kind[e] != CSIM_I) continue;
+        const int s = ir.param_slot[e], tb = ap.termBase[static_cast<std::size_t>(e)];
+        const std::string name = "sv" + std::to_string(e);
+        auto PX = [&](int o) { return "params[" + std::to_string(s + o) + "LL * SB + bb]"; };
+        srcCode << "    const double " << name << " = " << (ir.wave[e] == CSIM_WAVE_SIN ? "(" + PX(0) + " + " + PX(1) + ") * 1.0" : PX(0) + " * 1.0") << ";\n";
+        termS[static_cast<std::size_t>(tb + T_SRC_VAL)] = LV::dyn(name);
+    }
+    LGen gs;
+    gs.ind = "    ";
+    gs.prefix = "vd";
+    std::vector<LV> rhs(static_cast<std::size_t>(N));
+    std::vector<std::vector<LV>> rpend(static_cast<std::size_t>(N));
+    for (int n = 0; n < gpl.nnzI(); ++n) {
+        std::vector<LV> terms;
+        for (int c = gpl.iPtr[static_cast<std::size_t>(n)]; c < gpl.iPtr[static_cast<std::size_t>(n + 1)]; ++c) {
+            const int con = gpl.iCon[static_cast<std::size_t>(c)];
+            LV t = termS[static_cast<std::size_t>(con >> 1)];
+            terms.push_back((con & 1) ? gs.negate(t) : t);
+        }
+        rpend[static_cast<std::size_t>(gpl.iRow[static_cast<std::size_t>(n)])] = terms;
+        rhs[static_cast<std::size_t>(gpl.iRow[static_cast<std::size_t>(n)])] = LV::dyn("?");
+    }
+    auto bAt = [&](int r) -> LV& {
+        if (!rpend[static_cast<std::size_t>(r)].empty()) { rhs[static_cast<std::size_t>(r)] = gs.orderedSum(rpend[static_cast<std::size_t>(r)]); rpend[static_cast<std::size_t>(r)].clear(); }
+        if (rhs[static_cast<std::size_t>(r)].kind == LV::DYN && rhs[static_cast<std::size_t>(r)].e == "?") rhs[static_cast<std::size_t>(r)] = LV();
+        return rhs[static_cast<std::size_t>(r)];
+    };
+    {
+        std::size_t op = 0;
+        for (int k = 0; k < N; ++k) {
+            const int p = F.swapWith[static_cast<std::size_t>(k)];
+            if (p != k) { std::swap(rhs[static_cast<std::size_t>(p)], rhs[static_cast<std::size_t>(k)]); std::swap(rpend[static_cast<std::size_t>(p)], rpend[static_cast<std::size_t>(k)]); }
+            if ((k % 4) == 0) gs.out << gs.ind << "__builtin_amdgcn_sched_barrier(0);\n";
+            for (; op < F.fwd.size() && F.fwd[op].k == k; ++op) {
+                const LV bk = bAt(k);
+                if (bk.zero()) continue;
+                const LV bi = bAt(F.fwd[op].i);
+                rhs[static_cast<std::size_t>(F.fwd[op].i)] = gs.fnma(bi, F.fwd[op].f, bk);
+            }
+        }
+    }
+    gs.out << gs.ind << "// back substitution (solver.hpp:116-128)\n";
+    std::vector<LV> xr(static_cast<std::size_t>(N));
+    for (int i = N - 1; i >= 0; --i) {
+        if ((i % 4) == 0) gs.out << gs.ind << "__builtin_amdgcn_sched_barrier(0);\n";
+        LV sum = bAt(i);
+        for (int j = i + 1; j < N; ++j) {
+            const LV& u = F.U[static_cast<std::size_t>(i)][static_cast<std::size_t>(j)];
+            if (u.zero()) continue;
+            sum = gs.fnma(sum, u, xr[static_cast<std::size_t>(j)]);
+        }
+        LV x;
+        if (sum.zero()) {
+            // a structurally zero sum still goes through the division: +0 / U(i,i) is -0 for a negative pivot, and the
+            // operating point is an OUTPUT (the t = 0 row of the reference's CSV prints the sign)
+            const LV& pv = F.piv[static_cast<std::size_t>(i)];
+            x = gs.emit(pv.kind == LV::CONST ? lit(0.0 / pv.c) : "0.0 / " + gs.ref(pv));
+        } else {
+            x = emitQuotient(gs, sum, F.piv[static_cast<std::size_t>(i)], F.rinv[static_cast<std::size_t>(i)]);
+            if (x.kind == LV::DYN && (x.e.compare(0, 2, "vd") != 0 || x.neg)) x = gs.emit(gs.ref(x));
+        }
+        gs.out << gs.ind << "if (ok) xout[" << i << "LL * SB + b] = " << gs.ref(x) << ";\n";
+        xr[static_cast<std::size_t>(i)] = x;
+    }
+    // tape positions in the order of the solve's reads
+    std::string solveText = gs.out.str();
+    std::vector<std::vector<int>> uses(static_cast<std::size_t>(F.nHandles));
+    int nTape = 0;
+    {
+        std::string outText;
+        std::size_t i = 0;
+        while (i < solveText.size()) {
+            const std::size_t a = solveText.find("@L", i);
+            if (a == std::string::npos) { outText += solveText.substr(i); break; }
+            const std::size_t b = solveText.find('@', a + 2);
+            const int h = std::atoi(solveText.substr(a + 2, b - a - 2).c_str());
+            outText += solveText.substr(i, a - i) + "TP(" + std::to_string(nTape) + ")";
+            uses[static_cast<std::size_t>(h)].push_back(nTape++);
+            i = b + 1;
+        }
+        solveText = outText;
+    }
+    if (nTape == 0) nTape = 1;
+    std::ostringstream o;
+    o << "// ---- linear circuit: DC operating point, one direct solve (codegen_linear.cpp emitLinearDcKernel)\n"
+      << linearPrelude()
+      << "// DC pivot schedule: " << (sc.str().empty() ? std::string("-") : sc.str()) << "\n"
+      << "#pragma clang fp contract(off)\n"
+      << "extern \"C\" __global__ void __launch_bounds__(64)\n"
+      << "csim_dc_linear_kernel(const double* __restrict__ params, int B, double* __restrict__ xout, int* __restrict__ iters,\n"
+      << "                      unsigned* __restrict__ status, unsigned char* __restrict__ fallback, int* __restrict__ violFlag,\n"
+      << "                      const unsigned char* __restrict__ only, double* __restrict__ work)\n{\n"
+      << "    const int b = blockIdx.x * 64 + threadIdx.x;\n"
+      << "    const bool inb = b < B && (!only || only[b < B ? b : 0] != 0);\n"
+      << "    if (!__any(inb)) return;\n"
+      << "    const long long bb = b < B ? b : B - 1;\n"
+      << "    const long long SB = B, SBW = ((long long)B + 63) / 64 * 64;\n"
+      << "    const double dt = 0.0;                              // no companion models at DC\n"
+      << "    const long long vo0 = (B < 0) ? 1LL : 0LL;          // always 0, opaque to the compiler\n"
+      << "    double* const tapeW = work + b;\n"
+      << "    const double* const tapeF = tapeW + vo0;\n"
+      << "    const double* const tapeR = tapeW + vo0;\n"
+      << "#define TW(n) tapeW[(long long)(n) * SBW]\n"
+      << "#define TF(n) tapeF[(long long)(n) * SBW]\n"
+      << "#define TP(n) tapeR[(long long)(n) * SBW]\n"
+      << "    bool viol = false;\n"
+      << "    (void)dt;\n"
+      << resolveFactorText(F.text, uses)
+      << "    viol = viol || pvF != 0;\n"
+      << "    const bool ok = inb && !viol;\n"
+      << srcCode.str()
+      << solveText
+      << "    if (inb) {\n"
+      << "        if (viol) { fallback[b] = 1; violFlag[0] = 1; }     // the general kernel solves this instance\n"
+      << "        else { iters[b] = 1; status[b] = 0u; }\n"
+      << "    }\n"
+      << "#undef TW\n#undef TF\n#undef TP\n"
+      << "}\n#pragma clang fp contract(fast)\n\n";
+    if (workDoubles) *workDoubles = nTape;
     return o.str();
 }
 

@@ -149,7 +149,11 @@ void adoptScheduleTable(csim_engine* eng, void* lib)
     eng->schedHasFaithful = faithFn && faithFn() != 0;
     if (eng->kernelChoice == 3 && !eng->schedHasFaithful) eng->kernelChoice = 0;    // a reload dropped the faithful kernel
     LanesFn workFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_work_doubles"));
-    eng->schedWorkDoubles = workFn ? workFn() : 0;
+    {
+        const int need = workFn ? workFn() : 0;
+        if (need != eng->schedWorkDoubles) eng->schedWorkCap = 0;        // another library: its work area has another size
+        eng->schedWorkDoubles = need;
+    }
     // DC operating-point kernel, present when the library was generated with "dc" schedules
     eng->schedDcLaunch = nullptr;
     if (AltsFn dcAlts = reinterpret_cast<AltsFn>(dlsym(lib, "csim_sched_dc_alts"))) {
@@ -430,6 +434,18 @@ static int ensureFallbackBuffers(csim_engine* eng, int32_t B)
     return CSIM_OK;
 }
 
+// work area of a linear circuit's generated kernels (their factor tape)
+static int ensureSchedWork(csim_engine* eng, int32_t B)
+{
+    if (eng->schedWorkDoubles <= 0 || eng->schedWorkCap >= B) return CSIM_OK;
+    if (eng->dSchedWork) HIPCHK(hipFree(eng->dSchedWork));
+    eng->dSchedWork = nullptr;
+    eng->schedWorkCap = 0;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dSchedWork), sizeof(double) * (size_t)eng->schedWorkDoubles * ((size_t)B + 64)));   // whole workgroups
+    eng->schedWorkCap = B;
+    return CSIM_OK;
+}
+
 // buffers of the near-threshold verification (kernels_verify.hip)
 static int ensureNearBuffers(csim_engine* eng, int32_t B)
 {
@@ -464,13 +480,18 @@ int csim_dc_batch_dev(csim_engine* eng, const double* d_params, int32_t B, doubl
     }
     if (B == 0) return CSIM_OK;
     HIPCHK(hipSetDevice(eng->device));
-    if (eng->big) {
-        const int rc = ensureBigScratch(eng, B, static_cast<hipStream_t>(stream));
-        if (rc) return rc;
-        HIPCHK(csim::launchDcBig(eng->gpDc, d_params, B, eng->dBigScratch, d_x, d_iters, d_status, static_cast<hipStream_t>(stream)));
-        return CSIM_OK;
-    }
     hipStream_t hs = static_cast<hipStream_t>(stream);
+    // the kernels with run-time pivoting: every instance, or the ones a mask names
+    auto generalDc = [&](const unsigned char* only) -> int {
+        if (eng->big) {
+            const int rc = ensureBigScratch(eng, B, hs);
+            if (rc) return rc;
+            HIPCHK(csim::launchDcBig(eng->gpDc, d_params, B, eng->dBigScratch, d_x, d_iters, d_status, hs, only));
+        } else {
+            HIPCHK(csim::launchDcGeneral(eng->gpDc, d_params, B, d_x, d_iters, d_status, hs, only));
+        }
+        return CSIM_OK;
+    };
     if (eng->schedDcLaunch && eng->kernelChoice != 1) {
         // Generated lane-per-instance kernels on the recorded DC pivot sequences, as a chain in which every
         // kernel replays, from x = 0, exactly the instances the one before could not finish (mask):
@@ -480,14 +501,15 @@ int csim_dc_batch_dev(csim_engine* eng, const double* d_params, int32_t B, doubl
         //   faithful kernel: the reference's operations, bit for bit the general kernel's operating points;
         //    leaves an instance on a failed pivot check or a non-finite solve ->
         //   general kernel (run-time pivoting).
-        const int rc = ensureFallbackBuffers(eng, B);
+        int rc = ensureFallbackBuffers(eng, B);
+        if (!rc) rc = ensureSchedWork(eng, B);
         if (rc) return rc;
         const bool sync = eng->cfg.hybridSync;
-        const bool fast = eng->cfg.dcFast && eng->kernelChoice != 3;
+        const bool fast = eng->cfg.dcFast && eng->kernelChoice != 3 && eng->schedLinearLanes == 0;
         auto stage = [&](int variant, unsigned char* leaves, const unsigned char* only, bool* any) -> int {
             HIPCHK(hipMemsetAsync(leaves, 0, (size_t)B, hs));
             HIPCHK(hipMemsetAsync(eng->dViolFlag, 0, 4 * sizeof(int32_t), hs));
-            if (eng->schedDcLaunch(d_params, B, d_x, d_iters, d_status, leaves, eng->dViolFlag, only, stream, variant) != 0) {
+            if (eng->schedDcLaunch(d_params, B, d_x, d_iters, d_status, leaves, eng->dViolFlag, only, eng->dSchedWork, stream, variant) != 0) {
                 setError("scheduled DC kernel launch failed");
                 return CSIM_ERR_HIP;
             }
@@ -504,11 +526,9 @@ int csim_dc_batch_dev(csim_engine* eng, const double* d_params, int32_t B, doubl
         unsigned char* mine = fast ? eng->dFallback2 : eng->dFallback;
         if (const int frc = stage(0, mine, left, &any)) return frc;
         if (!any) return CSIM_OK;
-        HIPCHK(csim::launchDcGeneral(eng->gpDc, d_params, B, d_x, d_iters, d_status, hs, mine));
-        return CSIM_OK;
+        return generalDc(mine);
     }
-    HIPCHK(csim::launchDcGeneral(eng->gpDc, d_params, B, d_x, d_iters, d_status, hs));
-    return CSIM_OK;
+    return generalDc(nullptr);
 }
 
 int csim_tran_batch_dev(csim_engine* eng, const double* d_params, int32_t B, double tstep,
@@ -590,12 +610,9 @@ int csim_tran_batch_dev(csim_engine* eng, const double* d_params, int32_t B, dou
     HIPCHK(hipMemsetAsync(eng->dDone, 0, sizeof(int32_t) * (size_t)B, hs));
     HIPCHK(hipMemsetAsync(eng->dViolFlag, 0, 8 * sizeof(int32_t), hs));
     if (!linearLib) HIPCHK(hipMemsetAsync(eng->dNearStep, 0, sizeof(int32_t) * (size_t)B, hs));
-    if (linearLib && eng->schedWorkCap < B) {      // factor store of the linear-circuit kernel
-        if (eng->dSchedWork) HIPCHK(hipFree(eng->dSchedWork));
-        eng->dSchedWork = nullptr;
-        eng->schedWorkCap = 0;
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&eng->dSchedWork), sizeof(double) * (size_t)eng->schedWorkDoubles * ((size_t)B + 64)));   // whole workgroups
-        eng->schedWorkCap = B;
+    if (linearLib) {                               // factor store of the linear-circuit kernels
+        const int rc = ensureSchedWork(eng, B);
+        if (rc) return rc;
     }
     const bool sync = eng->cfg.hybridSync;
     csim_sched_aux aux{eng->dFallback, eng->dDone, eng->dViolFlag, eng->dSchedWork,
@@ -1089,7 +1106,6 @@ int csim_record_dc_pivot_schedules(csim_engine* eng, const double* d_params, int
         setError("csim_record_dc_pivot_schedules: bad argument");
         return CSIM_ERR_ARG;
     }
-    if (eng->big) { setError("the DC planner covers circuits of up to 63 unknowns"); return CSIM_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(eng->device));
     const int N = eng->plan.N;
     const int logInts = csim::pivlog_ints(N);
@@ -1103,8 +1119,15 @@ int csim_record_dc_pivot_schedules(csim_engine* eng, const double* d_params, int
     HIPCHK(hipMemset(dOnly.p, 0, (size_t)B));
     const unsigned char one = 1;
     HIPCHK(hipMemcpy(dOnly.as<unsigned char>() + instance, &one, 1, hipMemcpyHostToDevice));
-    HIPCHK(csim::launchDcGeneral(eng->gpDc, d_params, B, dX.as<double>(), dIt32.as<int32_t>(), dSt.as<uint32_t>(), nullptr,
-                                 dOnly.as<uint8_t>(), dLog.as<int32_t>(), instance));
+    if (eng->big) {
+        const int rc = ensureBigScratch(eng, B, nullptr);
+        if (rc) return rc;
+        HIPCHK(csim::launchDcBig(eng->gpDc, d_params, B, eng->dBigScratch, dX.as<double>(), dIt32.as<int32_t>(), dSt.as<uint32_t>(),
+                                 nullptr, dOnly.as<uint8_t>(), dLog.as<int32_t>(), instance));
+    } else {
+        HIPCHK(csim::launchDcGeneral(eng->gpDc, d_params, B, dX.as<double>(), dIt32.as<int32_t>(), dSt.as<uint32_t>(), nullptr,
+                                     dOnly.as<uint8_t>(), dLog.as<int32_t>(), instance));
+    }
     HIPCHK(hipDeviceSynchronize());
     std::vector<int32_t> log((size_t)logInts);
     HIPCHK(hipMemcpy(log.data(), dLog.p, sizeof(int32_t) * log.size(), hipMemcpyDeviceToHost));
@@ -1280,7 +1303,19 @@ int csim_engine_jit_scheduled(csim_engine* eng, const double* d_params, int32_t 
     // but only when a few sequences cover that instance's whole ramp: a circuit that walks through many
     // (buffer.sp: 10) would fail its checks in most instances and pay for both kernels.
     // cfg.jitDcAlts = limit (default 4, at most 8); cfg.jitDcForce keeps a partial cover (tests).
-    if (ir->has_nonlinear && !eng->big) {
+    if (!ir->has_nonlinear) {
+        // a linear circuit's operating point is ONE factorisation (dcSolveDirectLU): its pivot sequence, planned on instance 0
+        std::vector<int32_t> dpos((size_t)N);
+        int32_t nDc = 0;
+        int64_t dcOther = 0;
+        rc = csim_record_dc_pivot_schedules(eng, d_params, B, 0, 1, dpos.data(), nullptr, &nDc, &dcOther);
+        if (rc) return rc;
+        if (nDc == 1) {
+            csim::PivotSchedule one = csim::PivotSchedule::identity(N);
+            for (int k = 0; k < N; ++k) one.pivotPos[(size_t)k] = dpos[(size_t)k];
+            sch.dcAlts.push_back(one);
+        }
+    } else if (!eng->big) {
         const int planMax = 8;
         const int limit = eng->cfg.jitDcAlts;
         const bool force = eng->cfg.jitDcForce;

@@ -61,7 +61,7 @@ struct csim_engine {
     typedef int (*SchedLaunchFn)(const double*, int, double, long long, long long, const int*, int, int,
                                  double*, double*, long long*, unsigned*, int*, const csim_sched_aux*, void*, int);
     // DC operating point of the same library (nullptr: the library carries no DC schedule)
-    typedef int (*SchedDcLaunchFn)(const double*, int, double*, int*, unsigned*, unsigned char*, int*, const unsigned char*, void*, int);
+    typedef int (*SchedDcLaunchFn)(const double*, int, double*, int*, unsigned*, unsigned char*, int*, const unsigned char*, double*, void*, int);
     void* schedLib = nullptr;
     SchedLaunchFn schedLaunch = nullptr;
     SchedDcLaunchFn schedDcLaunch = nullptr;

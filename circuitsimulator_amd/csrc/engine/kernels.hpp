@@ -48,7 +48,8 @@ size_t bigScratchBytesPerInstance(const GenPlan& pl);
 int bigMaxUnknowns();
 bool bigSupports(int N, int nTerms, int P);
 hipError_t launchDcBig(const GenPlan& pl, const double* dParams, int B, double* dScratch, double* dX,
-                       int32_t* dIters, uint32_t* dStatus, hipStream_t stream);
+                       int32_t* dIters, uint32_t* dStatus, hipStream_t stream, const uint8_t* dOnly = nullptr,
+                       int32_t* dPivLog = nullptr, int pivInstance = 0);
 hipError_t launchTranBig(const GenPlan& pl, const double* dParams, int B, double dt, long long stepFirst,
                          long long nSteps, const int32_t* dProbeEq, int nProbe, int outStride, double* dWave,
                          double* dX, long long* dIters, uint32_t* dStatus, int32_t* dStepIters,

@@ -275,11 +275,14 @@ __device__ __forceinline__ bool all_finite_big(const double* v, int N, int lane)
 // ------------------------------------------------------------------ DC
 __global__ void __launch_bounds__(64)
 k_dc_big(GenPlan pl, const double* __restrict__ params, int B, double* __restrict__ scratch,
-         double* __restrict__ xout, int32_t* __restrict__ iters, uint32_t* __restrict__ status)
+         double* __restrict__ xout, int32_t* __restrict__ iters, uint32_t* __restrict__ status,
+         const uint8_t* __restrict__ only, int32_t* __restrict__ pivLog, int pivInstance)
 {
     extern __shared__ unsigned char smraw[];
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
+    if (only && !only[b]) return;           // fallback / planner launches touch the flagged instances only
+    int32_t* myPivLog = (pivLog && b == pivInstance) ? pivLog : nullptr;
     const int N = pl.N;
     const BigLds L = carve(smraw, N, pl.nTerms, pl.P);
     double* Gg = scratch + (size_t)b * N * pl.LD;
@@ -299,7 +302,7 @@ k_dc_big(GenPlan pl, const double* __restrict__ params, int B, double* __restric
         if (lane == 0) L.T[pl.termGmin] = 0.0;
         wave_sync();
         assemble_big(pl, L, Gg, lane);
-        lu_solve_big(pl, L, Gg, K.lu_eps, lane, st, nullptr);
+        lu_solve_big(pl, L, Gg, K.lu_eps, lane, st, myPivLog);
         clear_big(pl, L, Gg, lane);
         for (int i = lane; i < N; i += 64) L.xs[i] = L.xr[i];
         itTotal = 1;
@@ -348,7 +351,7 @@ k_dc_big(GenPlan pl, const double* __restrict__ params, int B, double* __restric
     }
     wave_sync();
     for (int i = lane; i < N; i += 64) xout[(int64_t)i * B + b] = L.xs[i];
-    if (lane == 0) { iters[b] = itTotal; status[b] = st; }
+    if (lane == 0) { iters[b] = itTotal; status[b] = (only && !pivLog) ? (st | CSIM_ST_SCHED_FALLBACK_DC) : st; }
 }
 
 // ------------------------------------------------------------ transient
@@ -451,12 +454,14 @@ int bigMaxUnknowns() { return BIG_MAX_N; }
 bool bigSupports(int N, int nTerms, int P) { return N <= BIG_MAX_N && bigLdsBytes(N, nTerms, P) <= 160 * 1024; }
 
 hipError_t launchDcBig(const GenPlan& pl, const double* dParams, int B, double* dScratch, double* dX,
-                       int32_t* dIters, uint32_t* dStatus, hipStream_t stream)
+                       int32_t* dIters, uint32_t* dStatus, hipStream_t stream, const uint8_t* dOnly, int32_t* dPivLog,
+                       int pivInstance)
 {
     const size_t lds = bigLdsBytes(pl.N, pl.nTerms, pl.P);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dc_big), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_dc_big, dim3(B), dim3(64), lds, stream, pl, dParams, B, dScratch, dX, dIters, dStatus);
+    hipLaunchKernelGGL(k_dc_big, dim3(B), dim3(64), lds, stream, pl, dParams, B, dScratch, dX, dIters, dStatus, dOnly, dPivLog,
+                       pivInstance);
     return hipGetLastError();
 }
 
