@@ -62,11 +62,15 @@ def test_linear_kernels_are_bitwise_the_general_kernel(torch_mod, tmp_path, monk
     assert eng.tran_kernel == "scheduled"
     got = _run_tran(torch_mod, eng, params, steps, nl.tstep, probes=probes, stride=3, want_step_iters=True, chunks=[30, 50])
     assert not (got["status"] & 0x27).any()
-    # the operating point: the generated direct-solve kernel (dcSolveDirectLU on the recorded DC pivots), same bits, signs of
-    # zeros included, and it did the work itself (no instance replayed by the general kernel)
+    # the operating point, same bits, signs of zeros included.  rlc_mesh: the generated direct-solve kernel
+    # (dcSolveDirectLU on the recorded DC pivot sequence) did the work itself; the ladder's DC pivots differ from instance
+    # to instance (a resistor chain with its capacitors open: pivots win by a fraction of a percent), so the JIT gives it
+    # no DC kernel and the general kernel solves
     assert np.array_equal(got["dc_iters"], ref["dc_iters"]) and (got["dc_iters"] == 1).all()
     assert np.array_equal(got["x_dc"], ref["x_dc"]) and np.array_equal(np.signbit(got["x_dc"]), np.signbit(ref["x_dc"]))
     assert not (got["status"] & 0x80).any()
+    src = open(tmp_path / "jit" / [f for f in os.listdir(tmp_path / "jit") if f.endswith(".hip")][0]).read()
+    assert ("csim_dc_linear_kernel(" in src) == (name == "rlc_mesh")
     assert np.array_equal(got["step_iters"], ref["step_iters"])
     assert np.array_equal(got["status"] & NOFB, ref["status"])
     assert np.array_equal(got["x"], ref["x"]), np.abs(got["x"] - ref["x"]).max()
@@ -107,19 +111,4 @@ def test_ladder_sixteen_lane_kernel_is_the_one_that_runs(torch_mod, tmp_path, mo
     assert got["iters"][0] == 1687
     assert np.array_equal(got["step_iters"], ref["step_iters"])
     assert np.array_equal(got["x"], ref["x"])
-    assert "csim_dc_linear_kernel" in open(jit_dir / src[0]).read()
     assert np.array_equal(got["x_dc"], ref["x_dc"]) and not (got["status"] & 0x80).any()
-    # DC timing of the configs[3] share: generated direct solve against the large-N general kernel
-    import time
-    p8k = eng.mc_params(12345, 0.05, 0, 8192)
-    t = {}
-    for kern in ("general", "auto"):
-        eng.set_kernel(kern)
-        eng.dc(p8k)
-        torch_mod.cuda.synchronize()
-        t0 = time.perf_counter()
-        xk, itk, stk = eng.dc(p8k)
-        torch_mod.cuda.synchronize()
-        t[kern] = (time.perf_counter() - t0, xk)
-    print("ladder N = 257, 8192 operating points: general %.2f ms, generated %.2f ms" % (1e3 * t["general"][0], 1e3 * t["auto"][0]))
-    assert torch_mod.equal(t["general"][1], t["auto"][1])
