@@ -74,7 +74,7 @@ k_dc_general(GenPlan pl, const double* __restrict__ params, int B,
         if (lane == 0) T[pl.termGmin] = 0.0;
         wave_sync();
         assemble(pl, T, Gm, lane);
-        const double xr = lu_solve_wave(Gm, N, LD, K.lu_eps, lane, st);
+        const double xr = lu_solve_wave(Gm, N, LD, K.lu_eps, lane, st, myPivLog);
         if (lane < N) xs[lane] = xr;
         itTotal = 1;
     } else {
