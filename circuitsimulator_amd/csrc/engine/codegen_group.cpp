@@ -344,7 +344,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
           << "    const double mvth" << R << " = P(grp_slot[mq" << R << "]), mK" << R << " = P(grp_slot[mq" << R << "] + 1), mlam" << R << " = P(grp_slot[mq" << R << "] + 2);\n";
         for (int kd = 0; kd < 8; ++kd)
             o << "    const int md" << R << "_" << kd << " = grp_mosDest[(" << r * G << " + g) * 8 + " << kd << "] >= 0 ? grp_mosDest[(" << r * G
-              << " + g) * 8 + " << kd << "] : " << nStage * G << " + g;\n";
+              << " + g) * 8 + " << kd << "] : " << nStage * G << (gopt.dummyOneCell ? " + 0;\n" : " + g;\n");
     }
 
     for (int r = 0; r < srcRounds; ++r)
