@@ -84,7 +84,10 @@ struct GeneratorOptions {
                                  // (measured, profiles/r03_group16_b4096_*: SQ_LDS_BANK_CONFLICT 30.9 % of the LDS-active cycles
                                  // either way -- the conflicts come from the per-lane gathers / scatters of the MOSFET pass, not
                                  // from the [row][16] reads -- and 0.8 % slower padded)
-    int dummyOneCell = 0;        // sixteen-lane kernel: lanes without a MOSFET scatter into ONE dummy cell instead of one each (bank-conflict probe)
+    int dummyOneCell = 1;        // sixteen-lane kernel: lanes without a MOSFET (and stamps to ground) scatter into ONE dummy cell per instance
+                                 // instead of one each: writes to one address do not conflict, sixteen scattered dummies did with the real
+                                 // destinations (SQ_LDS_BANK_CONFLICT 3.85e8 -> 2.97e8 per launch, 30.8 % -> 25.6 % of the LDS-active
+                                 // cycles; +0.4 % on the bench, same box: gpurun_out/r03v)
     int linFactorBlock = 64;     // linear sixteen-lane library: lanes per workgroup of the factor kernel (0 = 16 / 32 / 64 by batch size;
                                  // measured on the N = 257 ladder at B = 8192, same box: 64 -> 3.09 ms per launch, by batch size (16) -> 3.16 ms)
     int linSrcLds = 1;           // linear sixteen-lane kernel: 1 = the sources' parameters are copied to LDS once per launch
@@ -94,7 +97,7 @@ struct GeneratorOptions {
 };
 
 // bumped whenever the emitted code or the launcher ABI of a generated library changes
-constexpr int kGeneratorRevision = 35;
+constexpr int kGeneratorRevision = 36;
 
 // identifies (topology, constants, schedule); names the generated library
 uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch);
