@@ -1021,6 +1021,7 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
                    << in << W(P) << " = fma(-" << t << ", " << MK(P) << ", " << W(P) << ");\n";
                 nChainInstr += 3;
                 bzero[sz(P)] = 0;
+                if (gopt.linChainBarrier && P == k + 1) ch << in << "__builtin_amdgcn_sched_barrier(0);\n";
                 continue;
             }
             if (lastSrc != k) {
@@ -1038,6 +1039,10 @@ std::string emitLinearGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, con
             ch << in << W(P) << " = fma(-" << t << ", " << MK(P) << ", " << W(P) << ");\n";
             ++nChainInstr;
             bzero[sz(P)] = 0;
+            // The operation that finishes the NEXT column's source row is the chain's critical link: a scheduling barrier
+            // after it keeps the column's other operations (the border row's) behind it, where they fill the wait states
+            // between this result and the DPP broadcast that reads it (the compiler otherwise emits them in front).
+            if (gopt.linChainBarrier && P == k + 1) ch << in << "__builtin_amdgcn_sched_barrier(0);\n";
         }
     }
     ch << in << "// back substitution (solver.hpp:116-128): row i = N-1 .. 0, columns j ascending\n";
