@@ -31,14 +31,18 @@ int mosStampKind(int termOffset, bool neg)
 } // namespace
 
 bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch, GroupPlan& gp,
-                    const GroupPlan* placement)
+                    const GroupPlan* placement, int lanes)
 {
     const int N = ir.n_unknowns;
     gp = GroupPlan();
-    if (N <= 0 || N > 4 * kGroupLanes) return false;         // four slots: the live classes of N = 57 still compile (106 spilled registers)
+    const int G = lanes;                                     // lanes per instance: 16 (a DPP row) or 4 (a quad)
+    if (G != 16 && G != 4) return false;
+    const unsigned laneAll = (1u << G) - 1u;
+    gp.G = G;
+    if (N <= 0 || N > (G == 16 ? 4 : 8) * G) return false;         // four slots: the live classes of N = 57 still compile (106 spilled registers)
     if (static_cast<int>(sch.pivotPos.size()) != N) return false;
     gp.N = N;
-    gp.S = (N + kGroupLanes - 1) / kGroupLanes;
+    gp.S = (N + G - 1) / G;
     const int S = gp.S, LD = ap.LD;
     const GatherPlan& g = ap.tran;
 
@@ -126,8 +130,8 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
     } else {
         for (int r = 0; r < N; ++r) { gp.finalPos[static_cast<std::size_t>(r)] = pivotStep[static_cast<std::size_t>(r)]; gp.rowAtPos[static_cast<std::size_t>(pivotStep[static_cast<std::size_t>(r)])] = r; }
     }
-    auto slotOf = [&](int row) { return gp.finalPos[static_cast<std::size_t>(row)] / kGroupLanes; };
-    auto laneOf = [&](int row) { return gp.finalPos[static_cast<std::size_t>(row)] % kGroupLanes; };
+    auto slotOf = [&](int row) { return gp.finalPos[static_cast<std::size_t>(row)] / G; };
+    auto laneOf = [&](int row) { return gp.finalPos[static_cast<std::size_t>(row)] % G; };
 
     gp.classLive.assign(static_cast<std::size_t>(S), std::vector<uint8_t>(static_cast<std::size_t>(N + 1), 0));
     for (int s = 0; s < S; ++s) gp.classLive[static_cast<std::size_t>(s)][static_cast<std::size_t>(N)] = 1;   // right-hand sides always exist
@@ -155,16 +159,16 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
         auto maskOf = [&](int s) {
             GroupPlan::Column::SlotMask m;
             bool anyGone = false;
-            for (int lane = 0; lane < kGroupLanes; ++lane) {
-                const int pos = s * kGroupLanes + lane;
+            for (int lane = 0; lane < G; ++lane) {
+                const int pos = s * G + lane;
                 if (pos >= N) { m.lanes |= 1u << lane; continue; }            // no row there: its registers are exact zeros
                 const int R2 = gp.rowAtPos[static_cast<std::size_t>(pos)];
                 if (pivotStep[static_cast<std::size_t>(R2)] > k) m.lanes |= 1u << lane;
                 else anyGone = true;
             }
             m.keepAll = !anyGone;
-            for (int t = 0; t < kGroupLanes && !m.keepAll; ++t)
-                if (m.lanes == ((0xFFFFu << (t + 1)) & 0xFFFFu)) m.suffix = t;
+            for (int t = 0; t < G && !m.keepAll; ++t)
+                if (m.lanes == ((laneAll << (t + 1)) & laneAll)) m.suffix = t;
             return m;
         };
         col.checkMask.resize(static_cast<std::size_t>(S));
@@ -294,7 +298,7 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
                     gp.stageRows.push_back({s, colj});
                 }
                 const int kind = mosStampKind(offOfTerm[static_cast<std::size_t>(t)], neg);
-                gp.mosDest[static_cast<std::size_t>(m)][static_cast<std::size_t>(kind)] = it->second * kGroupLanes + lane;
+                gp.mosDest[static_cast<std::size_t>(m)][static_cast<std::size_t>(kind)] = it->second * G + lane;
                 continue;
             }
             if (rhs) continue;                                           // handled below (per-step gather)
@@ -302,9 +306,9 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
             if (ci == classIndex.end()) {
                 ci = classIndex.emplace(std::make_pair(s, colj), static_cast<int>(gp.gClasses.size())).first;
                 gp.gClasses.push_back({s, colj});
-                cellCon.resize(gp.gClasses.size() * kGroupLanes);
+                cellCon.resize(gp.gClasses.size() * G);
             }
-            cellCon[static_cast<std::size_t>(ci->second * kGroupLanes + lane)].push_back(con[c]);
+            cellCon[static_cast<std::size_t>(ci->second * G + lane)].push_back(con[c]);
         }
     };
     for (int n = 0; n < g.nnzG(); ++n) {
@@ -312,7 +316,7 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
         addCell(pos / LD, pos % LD, &g.gCon[static_cast<std::size_t>(g.gPtr[static_cast<std::size_t>(n)])],
                 g.gPtr[static_cast<std::size_t>(n + 1)] - g.gPtr[static_cast<std::size_t>(n)], false);
     }
-    std::vector<std::vector<int32_t>> rhsCon(static_cast<std::size_t>(S * kGroupLanes));
+    std::vector<std::vector<int32_t>> rhsCon(static_cast<std::size_t>(S * G));
     for (int n = 0; n < g.nnzI(); ++n) {
         const int row = g.iRow[static_cast<std::size_t>(n)];
         const int32_t* con = &g.iCon[static_cast<std::size_t>(g.iPtr[static_cast<std::size_t>(n)])];
@@ -320,7 +324,7 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
         addCell(row, N, con, cnt, true);
         for (int c = 0; c < cnt; ++c)
             if (mosOfTerm[static_cast<std::size_t>(con[c] >> 1)] < 0)
-                rhsCon[static_cast<std::size_t>(slotOf(row) * kGroupLanes + laneOf(row))].push_back(con[c]);
+                rhsCon[static_cast<std::size_t>(slotOf(row) * G + laneOf(row))].push_back(con[c]);
     }
     // staging rows are added in the order (class, round): sort them so, and remap
     {
@@ -335,7 +339,7 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
         gp.stageRows = rows;
         for (auto& d : gp.mosDest)
             for (int& cell : d)
-                if (cell >= 0) cell = newOf[static_cast<std::size_t>(cell / kGroupLanes)] * kGroupLanes + cell % kGroupLanes;
+                if (cell >= 0) cell = newOf[static_cast<std::size_t>(cell / G)] * G + cell % G;
     }
     // ---- critical path of one solve (dependent-issue latency model: every VALU result is usable lat
     // cycles after issue; the Newton-refined reciprocal is a chain of 1 + 4 operations)
@@ -397,7 +401,7 @@ void interpretGroupPlan(const GroupPlan& gp, const AssemblyPlan& ap, const csim_
 {
     bool wrongPlan = false;
     (void)ir;
-    const int N = gp.N, S = gp.S, G = kGroupLanes;
+    const int N = gp.N, S = gp.S, G = gp.G;
     // registers a[s][j][lane]
     std::vector<double> a(static_cast<std::size_t>(S) * (N + 1) * G, 0.0);
     auto A = [&](int s, int j, int lane) -> double& { return a[(static_cast<std::size_t>(s) * (N + 1) + j) * G + lane]; };

@@ -45,7 +45,8 @@ namespace csim {
 constexpr int kGroupLanes = 16;
 
 struct GroupPlan {
-    int N = 0, S = 0;                        // unknowns, slots per lane = ceil(N / 16)
+    int N = 0, S = 0;                        // unknowns, slots per lane = ceil(N / G)
+    int G = kGroupLanes;                     // lanes per instance: 16 (one DPP row) or 4 (one quad; 16 instances per wavefront)
     std::vector<int> finalPos;               // original row -> pivot position
     std::vector<int> rowAtPos;               // pivot position -> original row
 
@@ -103,7 +104,7 @@ struct GroupPlan {
 // step-constant matrix part and the MOSFET staging: their pivot rows then sit at arbitrary lanes and the
 // finished rows of a slot are no longer a lane prefix (explicit lane masks instead of the mk factors).
 bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch, GroupPlan& out,
-                    const GroupPlan* placement = nullptr);
+                    const GroupPlan* placement = nullptr, int lanes = kGroupLanes);
 
 // Host interpreter of the plan, lane by lane, for ONE system: T[nTerms] are the term values of
 // plan.hpp.  Writes x[N]; *violated = a pivot check failed; *planError = a lane the kernel's all-lane

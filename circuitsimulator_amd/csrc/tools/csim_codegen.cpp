@@ -37,7 +37,7 @@ static std::string readSchedule(const std::string& path)
 
 // --selftest-group: run the sixteen-lanes-per-instance plan through its host interpreter on random term
 // values and compare with a plain dense elimination that uses the same pivot order (no GPU needed)
-static int selftestGroup(const csim_ir* ir, const csim::AssemblyPlan& ap, const csim::ScheduleSet& sch)
+static int selftestGroup(const csim_ir* ir, const csim::AssemblyPlan& ap, const csim::ScheduleSet& sch, int lanes)
 {
     int worstAlt = -1;
     double worst = 0.0;
@@ -45,7 +45,7 @@ static int selftestGroup(const csim_ir* ir, const csim::AssemblyPlan& ap, const 
     for (std::size_t alt = 0; alt < sch.alts.size(); ++alt) {
         csim::GroupPlan gp;
         // as the emitter does: alternatives are planned over the first schedule's row placement
-        if (!csim::buildGroupPlan(*ir, ap, sch.alts[alt], gp, alt ? &first : nullptr)) { std::printf("group plan: circuit does not fit\n"); return 3; }
+        if (!csim::buildGroupPlan(*ir, ap, sch.alts[alt], gp, alt ? &first : nullptr, lanes)) { std::printf("group plan: circuit does not fit\n"); return 3; }
         if (alt == 0) first = gp;
         const int N = ir->n_unknowns, LD = ap.LD;
         unsigned long long seed = 0x9E3779B97F4A7C15ull + alt;
@@ -121,7 +121,8 @@ int main(int argc, char** argv)
         argv += 2;
         argc -= 2;
     }
-    const bool selftest = argc >= 2 && std::string(argv[1]) == "--selftest-group";
+    const bool selftest4 = argc >= 2 && std::string(argv[1]) == "--selftest-group4";      // the plan for four lanes per instance
+    const bool selftest = selftest4 || (argc >= 2 && std::string(argv[1]) == "--selftest-group");
     const bool hashOnly = argc >= 2 && (std::string(argv[1]) == "--hash" || selftest);
     if ((hashOnly && argc != 4) || (!hashOnly && argc != 4)) {
         std::cerr << "usage: csim_codegen <netlist.sp> <schedule|-> <out.hip>\n"
@@ -147,7 +148,7 @@ int main(int argc, char** argv)
     // the library is NAMED by the topology hash (what an engine can compute before it
     // knows any schedule); the full hash is embedded for diagnostics
     const unsigned long long topo = csim::scheduleHash(*ir, csim::PivotSchedule::identity(ir->n_unknowns));
-    if (selftest) return selftestGroup(ir, ap, sch);
+    if (selftest) return selftestGroup(ir, ap, sch, selftest4 ? 4 : 16);
     if (hashOnly) { std::printf("%016llx\n", topo); return 0; }
 
     std::string label = netlist;
