@@ -122,6 +122,7 @@ bool GeneratorOptions::set(const std::string& keyval)
     if (key == "lin_factor_block") { linFactorBlock = std::atoi(val.c_str()); return linFactorBlock == 0 || linFactorBlock == 16 || linFactorBlock == 32 || linFactorBlock == 64; }
     if (key == "lin_src_lds") { linSrcLds = std::atoi(val.c_str()) != 0 ? 1 : 0; return true; }
     if (key == "dummy_one_cell") { dummyOneCell = std::atoi(val.c_str()) != 0 ? 1 : 0; return true; }
+    if (key == "group4") { group4 = std::atoi(val.c_str()) != 0 ? 1 : 0; return true; }
     if (key == "lin_chain_barrier") { linChainBarrier = std::atoi(val.c_str()) != 0 ? 1 : 0; return true; }
     if (key == "sweep") {
         sweep.clear();
@@ -150,6 +151,7 @@ uint64_t scheduleHash(const csim_ir& ir, const ScheduleSet& set, const Generator
     mix(static_cast<uint64_t>(gopt.linSrcLds + 17) * 0x165667B19E3779F9ull);
     mix(static_cast<uint64_t>(gopt.dummyOneCell + 19) * 0x85EBCA77C2B2AE63ull);
     mix(static_cast<uint64_t>(gopt.linChainBarrier + 23) * 0x27D4EB2F165667C5ull);
+    if (gopt.group4) mix(static_cast<uint64_t>(gopt.group4 + 29) * 0x9FB21C651E98DF25ull);
     for (std::size_t a = 1; a < set.alts.size(); ++a) {
         h ^= 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
         for (int p : set.alts[a].pivotPos) { h ^= static_cast<uint64_t>(p + 1); h *= 1099511628211ull; }
@@ -1068,6 +1070,10 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     GroupPlan groupPlan;
     const std::string groupSrc = haveLinear ? std::string() : emitGroupKernel(ir, ap, set.alts, gopt, &groupPlan);
     const bool haveGroup = !groupSrc.empty();
+    // ... and its four-lanes-per-instance form for the batches between the two (generator option group4)
+    GroupPlan quadPlan;
+    const std::string quadSrc = (haveGroup && gopt.group4) ? emitGroupKernel(ir, ap, set.alts, gopt, &quadPlan, 4) : std::string();
+    const bool haveQuad = !quadSrc.empty();
     if (haveLinear16 || haveGroup) src << groupPreludeSource(ir);
     src << lin16Src << linSrc;
     // DC operating point of a linear circuit on its recorded DC pivot sequence (one direct solve)
@@ -1142,7 +1148,7 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     }
     const bool haveDc = ldsDc >= 0;
 
-    src << groupSrc;
+    src << groupSrc << quadSrc;
 
     char hbuf[32];
     std::snprintf(hbuf, sizeof hbuf, "0x%016llxull", static_cast<unsigned long long>(hash));
@@ -1158,6 +1164,9 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     if (haveGroup)
         src << " group16_wave_ops_per_solve: bcast=" << groupPlan.nBcast << " fma=" << groupPlan.nFma << " mul=" << groupPlan.nMul
             << " cmp=" << groupPlan.nCmp << " recip=" << groupPlan.nRecip;
+    if (haveQuad)
+        src << " group4_wave_ops_per_solve: bcast=" << quadPlan.nBcast << " fma=" << quadPlan.nFma << " mul=" << quadPlan.nMul
+            << " cmp=" << quadPlan.nCmp << " recip=" << quadPlan.nRecip;
     src << "\"; }\n"
         << "// doubles per instance of the work area csim_sched_launch needs (0: none): the linear-circuit kernel parks\n"
         << "// its factors there\n"
@@ -1166,6 +1175,8 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "extern \"C\" int csim_sched_has_faithful(void) { return " << (haveFaithful ? 1 : 0) << "; }\n"
         << "// 16 when this library also carries csim_tran_group_kernel (sixteen lanes per instance, one solve body per schedule)\n"
         << "extern \"C\" int csim_sched_group_lanes(void) { return " << (haveGroup ? 16 : 0) << "; }\n"
+        << "// 4 when this library also carries csim_tran_group4_kernel (four lanes per instance; csim_sched_launch variant 4)\n"
+        << "extern \"C\" int csim_sched_group4_lanes(void) { return " << (haveQuad ? 4 : 0) << "; }\n"
         << "// lanes per instance of the linear-circuit kernel: 16 (registers), 1 (LDS + streamed tape), 0 (not a linear circuit)\n"
         << "extern \"C\" int csim_sched_linear_lanes(void) { return " << (haveLinear16 ? 16 : (haveLinear ? 1 : 0)) << "; }\n";
     src << ""
@@ -1252,6 +1263,12 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
     if (haveGroup)
         src << "    if (variant == 16) {\n"
             << "        hipLaunchKernelGGL(csim_tran_group_kernel, dim3((unsigned)((B + 3) / 4)), dim3(64), 0, (hipStream_t)stream,\n"
+            << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
+            << "                           stepIters, CSIM_AUX_ARGS);\n"
+            << "        return (int)hipGetLastError();\n    }\n";
+    if (haveQuad)
+        src << "    if (variant == 4) {\n"
+            << "        hipLaunchKernelGGL(csim_q4::csim_tran_group4_kernel, dim3((unsigned)((B + 15) / 16)), dim3(64), 0, (hipStream_t)stream,\n"
             << "                           params, B, dt, stepFirst, nSteps, probeEq, nProbe, outStride, wave, xio, iters, status,\n"
             << "                           stepIters, CSIM_AUX_ARGS);\n"
             << "        return (int)hipGetLastError();\n    }\n";

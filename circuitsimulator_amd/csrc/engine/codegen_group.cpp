@@ -49,6 +49,18 @@ __device__ __forceinline__ double grp_sum16(double v)
     v += __builtin_amdgcn_update_dpp(0.0, v, 0x118, 0xF, 0xF, true);
     return grp_bc<15>(v);
 }
+// four lanes per instance: broadcast within a DPP quad (quad_perm [L,L,L,L]; two v_mov_b32_dpp -- the 64-bit DPP move
+// knows row_newbcast only) and the sum over a quad, result in every lane
+template <int L> __device__ __forceinline__ double grp_bc4(double v)
+{
+    return __builtin_amdgcn_update_dpp(0.0, v, L * 0x55, 0xF, 0xF, true);
+}
+__device__ __forceinline__ double grp_sum4(double v)
+{
+    v += __builtin_amdgcn_update_dpp(0.0, v, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0.0, v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+    return v;
+}
 // 1/a: v_rcp_f64 (measured: 2^-24.4 relative) and ONE cubic step r (1 + e + e^2), e = 1 - a r -- three dependent
 // FMAs where two quadratic steps take four; on 2^20 random operands both give the correctly rounded reciprocal,
 // bit for bit the same (tools/dev/ubench/rcp_acc.hip)
@@ -165,16 +177,16 @@ std::string groupPreludeSource(const csim_ir& ir)
 }
 
 std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std::vector<PivotSchedule>& schedules,
-                            const GeneratorOptions& gopt, GroupPlan* planOut)
+                            const GeneratorOptions& gopt, GroupPlan* planOut, int lanes)
 {
     if (schedules.empty()) return std::string();
     // The first (most frequent) schedule places the rows; the others are planned over that placement, so
     // that all solve bodies share the launch-constant matrix part, the staging rows and the scatter tables.
     std::vector<GroupPlan> plans(1);
-    if (!buildGroupPlan(ir, ap, schedules[0], plans[0])) return std::string();
+    if (!buildGroupPlan(ir, ap, schedules[0], plans[0], nullptr, lanes)) return std::string();
     for (std::size_t a = 1; a < schedules.size(); ++a) {
         GroupPlan alt;
-        if (!buildGroupPlan(ir, ap, schedules[a], alt, &plans[0])) return std::string();
+        if (!buildGroupPlan(ir, ap, schedules[a], alt, &plans[0], lanes)) return std::string();
         if (alt.gCellPtr != plans[0].gCellPtr || alt.gCellCon != plans[0].gCellCon || alt.iCellPtr != plans[0].iCellPtr ||
             alt.iCellCon != plans[0].iCellCon || alt.mosDest != plans[0].mosDest || alt.stageRows.size() != plans[0].stageRows.size() ||
             alt.gClasses.size() != plans[0].gClasses.size())
@@ -184,7 +196,10 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     const GroupPlan& gp = plans[0];
     if (planOut) *planOut = gp;
     const bool multi = plans.size() > 1;
-    const int N = gp.N, S = gp.S, G = kGroupLanes;
+    const int N = gp.N, S = gp.S, G = gp.G;
+    const bool quad = G != kGroupLanes;                        // four lanes per instance (DPP quads), 16 instances per wavefront
+    const int perWave = 64 / G;
+    const std::string GS = std::to_string(G), BC = quad ? "grp_bc4<" : "grp_bc<";
     const csim_consts& K = ir.k;
     const int NP = S * G;                                       // padded unknown count
     const int nMos = static_cast<int>(gp.mosElem.size());
@@ -193,18 +208,10 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     // near-threshold guard (codegen.hpp GeneratorOptions::nearBand)
     const bool guard = gopt.nearBand > 0.0;
 
-    // LDS carve-up per instance (doubles)
     const int nT1 = ap.nTerms + 1;                              // + one dummy term (always 0) for padded table entries
-    const int oXS = 0, oXP = oXS + NP + 1, oTT = oXP + NP + 1, oTS = oTT + nT1, oPL = oTS + 2 * nT1, oST = oPL + ir.n_params;
-    // Per-instance stride (generator option lds_pad): the four groups of a wave read the same [row][16] cells of their
-    // own instance in one ds_read_b64, 32 lanes (two groups) per pass over the 64 four-byte banks; a stride of 16
-    // doubles (mod 32) puts the second group of a pass on the other half of the banks.  Measured: no fewer conflicts
-    // (codegen.hpp), so off by default.
-    int instDoubles = oST + (nStage + 1) * G;
-    while (gopt.ldsPad && instDoubles % 32 != 16) ++instDoubles;
-    if (instDoubles * 8 * 4 > 150 * 1024) return std::string();  // one CU's LDS (a workgroup of four instances must fit)
 
     std::ostringstream o;      // (the shared device code, groupPreludeSource(), is emitted by the caller)
+    if (quad) o << "\nnamespace csim_q4 {   // (the tables below have the names of the 16-lane kernel's)\n";
 
     // ---- circuit tables
     {
@@ -232,11 +239,29 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     for (int e = 0; e < ir.n_elems; ++e) if (ir.kind[e] == CSIM_V || ir.kind[e] == CSIM_I) srcTab.push_back(e);
     const int srcRounds = (static_cast<int>(srcTab.size()) + G - 1) / G;
     srcTab.resize(static_cast<std::size_t>(std::max(1, srcRounds) * G), -1);
+    // quad: per-step terms (a source's value, a history term) get compact slots in TS; sources' parameters are packed
+    std::vector<int> stepSlot(static_cast<std::size_t>(nT1), -1);
+    std::vector<int32_t> srcOff(srcTab.size(), 0), srcSlot(srcTab.size(), 0);
+    int nSrcParams = 0, zeroSlot = 0;
+    if (quad)
+        for (std::size_t i = 0; i < srcTab.size(); ++i) {
+            const int e = srcTab[i];
+            if (e < 0) continue;
+            srcOff[i] = nSrcParams;
+            nSrcParams += (e + 1 < ir.n_elems ? ir.param_slot[e + 1] : ir.n_params) - ir.param_slot[e];
+            stepSlot[static_cast<std::size_t>(ap.termBase[static_cast<std::size_t>(e)])] = zeroSlot;
+            srcSlot[i] = zeroSlot++;
+        }
     std::vector<int32_t> hA, hG;
     {
         const int dummy = ap.nTerms;
-        auto node = [&](int eq) { return eq >= 0 ? eq : NP; };
-        auto add = [&](int gterm, int a, int b, int out) { hA.push_back(node(a) | (node(b) << 8)); hG.push_back(gterm | (out << 16)); };
+        // (quad: the history reads go through XH = XP - 1, whose entry 0 is the iterate's ground cell XS[NP])
+        auto node = [&](int eq) { return quad ? (eq >= 0 ? eq + 1 : 0) : (eq >= 0 ? eq : NP); };
+        auto add = [&](int gterm, int a, int b, int out) {
+            if (quad) { stepSlot[static_cast<std::size_t>(out)] = zeroSlot; out = zeroSlot++; }
+            hA.push_back(node(a) | (node(b) << 8));
+            hG.push_back(gterm | (out << 16));
+        };
         for (int e = 0; e < ir.n_elems; ++e) {
             const int tb = ap.termBase[static_cast<std::size_t>(e)];
             const int32_t* q = ir.eq + 4 * e;
@@ -249,7 +274,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
                 add(tb + T_M_GCF, q[0], q[3], tb + T_M_IHDB);
             }
         }
-        while (hA.size() % G) { hA.push_back(NP | (NP << 8)); hG.push_back(dummy | (dummy << 16)); }
+        while (hA.size() % G) { hA.push_back(node(-1) | (node(-1) << 8)); hG.push_back(dummy | ((quad ? zeroSlot : dummy) << 16)); }
         if (ap.nTerms >= 65535 || NP >= 255) return std::string();
     }
     const int histRounds = static_cast<int>(hA.size()) / G;
@@ -262,28 +287,64 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
         for (int t = 0; t < rhsMax[static_cast<std::size_t>(s)]; ++t)
             for (int lane = 0; lane < G; ++lane) {
                 const int lo = gp.iCellPtr[static_cast<std::size_t>(s * G + lane)], hi = gp.iCellPtr[static_cast<std::size_t>(s * G + lane + 1)];
-                rhsIdx.push_back(lo + t < hi ? gp.iCellCon[static_cast<std::size_t>(lo + t)] : 2 * ap.nTerms);   // padding: + the dummy zero
+                int con = lo + t < hi ? gp.iCellCon[static_cast<std::size_t>(lo + t)] : 2 * ap.nTerms;   // padding: + the dummy zero
+                if (quad) {
+                    const int sl = (con >> 1) == ap.nTerms ? zeroSlot : stepSlot[static_cast<std::size_t>(con >> 1)];
+                    if (sl < 0) return std::string();          // a right-hand-side term that is not a per-step term: cannot happen
+                    con = 2 * sl + (con & 1);
+                }
+                rhsIdx.push_back(con);
             }
     }
     o << intArray("grp_src", srcTab) << intArray("grp_hA", hA) << intArray("grp_hG", hG) << intArray("grp_rhs", rhsIdx);
+    if (quad) o << intArray("grp_srcOff", srcOff) << intArray("grp_srcSlot", srcSlot);
 
-    o << "\n// One DPP row of 16 lanes = one circuit instance, 4 instances per wavefront (group_plan.hpp).\n"
+    // LDS carve-up per instance (doubles)
+    int oXS = 0, oXP = oXS + NP + 1, oTT = oXP + NP + 1, oTS = oTT + nT1, oPL = oTS + 2 * nT1, oST = oPL + ir.n_params;
+    // Per-instance stride (generator option lds_pad): the four groups of a wave read the same [row][16] cells of their
+    // own instance in one ds_read_b64, 32 lanes (two groups) per pass over the 64 four-byte banks; a stride of 16
+    // doubles (mod 32) puts the second group of a pass on the other half of the banks.  Measured: no fewer conflicts
+    // (codegen.hpp), so off by default.
+    int instDoubles = oST + (nStage + 1) * G;
+    if (quad) {
+        // Four lanes per instance put 16 instances into a workgroup, and four workgroups must share a CU's 160 KB (one
+        // wave per SIMD): 320 doubles per instance.  So: only the sources' parameters (PL), only the per-step terms in
+        // TS (compact slots; zeroSlot = always 0), and TT -- needed while the launch-constant matrix part and the
+        // history coefficients are gathered, dead afterwards -- shares its place with TS and the staging rows.
+        // XP has no ground cell of its own (XH, above), and the staging rows' dummy is the one cell lanes without a
+        // MOSFET scatter into.  The stride is then padded to 4 (mod 8) doubles: a ds_read_b64 serves 32 lanes -- eight
+        // instances reading 8 consecutive dwords each -- per pass over the 64 banks, and with that stride the eight start
+        // on different multiples of 8 dwords (measured: a stride of 320 doubles, all instances on the same banks, cost
+        // 12 % of the kernel).
+        oPL = oXP + NP;
+        oTS = oPL + std::max(nSrcParams, 1);
+        oTT = oTS;
+        oST = oTS + 2 * (zeroSlot + 1);
+        instDoubles = std::max(oST + nStage * G + (gopt.dummyOneCell ? 1 : G), oTT + nT1);
+        while (instDoubles % 8 != 4) ++instDoubles;
+    }
+    while (gopt.ldsPad && instDoubles % 32 != 16) ++instDoubles;
+    if (instDoubles * 8 * perWave > 150 * 1024) return std::string();  // one CU's LDS (a workgroup of four instances must fit)
+
+
+    o << (quad ? "\n// One DPP quad of 4 lanes = one circuit instance, 16 instances per wavefront (group_plan.hpp).\n"
+               : "\n// One DPP row of 16 lanes = one circuit instance, 4 instances per wavefront (group_plan.hpp).\n")
       << "// pivot schedule" << (multi ? "s, tried in this order" : "") << ": " << [&] {
              std::string all;
              for (std::size_t a = 0; a < schedules.size(); ++a) all += (a ? " ; " : "") + (schedules[a].str().empty() ? std::string("-") : schedules[a].str());
              return all; }() << "\n"
       << "extern \"C\" __global__ void __launch_bounds__(64)"
       << (gopt.groupWavesPerEu > 0 ? " __attribute__((amdgpu_waves_per_eu(" + std::to_string(gopt.groupWavesPerEu) + ", " + std::to_string(gopt.groupWavesPerEu) + ")))" : std::string()) << "\n"
-      << "csim_tran_group_kernel(const double* __restrict__ params, int B, double dt, long long stepFirst,\n"
+      << (quad ? "csim_tran_group4_kernel" : "csim_tran_group_kernel") << "(const double* __restrict__ params, int B, double dt, long long stepFirst,\n"
       << "                       long long nSteps, const int* __restrict__ probeEq, int nProbe, int outStride,\n"
       << "                       double* __restrict__ wave, double* __restrict__ xio, long long* __restrict__ iters,\n"
       << "                       unsigned* __restrict__ status, int* __restrict__ stepIters,\n"
       << "                       unsigned char* __restrict__ fallback, int* __restrict__ done,\n"
       << "                       int* __restrict__ violFlag, double* __restrict__ nearX, int* __restrict__ nearStep,\n"
       << "                       int* __restrict__ nearIt, long long* __restrict__ nearItAfter)\n{\n"
-      << "    __shared__ double lds[4 * " << instDoubles << "];\n"
-      << "    const int lane = threadIdx.x, g = lane & 15, q = lane >> 4;\n"
-      << "    const int b = blockIdx.x * 4 + q;\n"
+      << "    __shared__ double lds[" << perWave << " * " << instDoubles << "];\n"
+      << "    const int lane = threadIdx.x, g = lane & " << G - 1 << ", q = lane >> " << (quad ? 2 : 4) << ";\n"
+      << "    const int b = blockIdx.x * " << perWave << " + q;\n"
       << "    const bool inb = b < B;\n"
       << "    const long long bb = inb ? b : B - 1;      // out-of-range groups shadow the last instance, never store\n"
       << "    const long long SB = B;\n"
@@ -294,18 +355,22 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
       << "    double* const TS = lds + q * " << instDoubles << " + " << oTS << ";   // per-step terms with sign: TS[2t] = +TT[t], TS[2t+1] = -TT[t]\n"
       << "    double* const PL = lds + q * " << instDoubles << " + " << oPL << ";   // this instance's parameters\n"
       << "    double* const ST = lds + q * " << instDoubles << " + " << oST << ";   // MOSFET staging rows [row][16]; last row = dummy\n"
-      << "    const unsigned long long rowBits = 0xFFFFull << (16 * q);\n"
+      << (quad ? "    double* const XH = XP - 1;          // history view of XP: XH[0] = XS[" + std::to_string(NP) + "] = 0 (ground), XH[1 + i] = XP[i]\n" : "")
+      << "    const unsigned long long rowBits = " << (quad ? "0xFull" : "0xFFFFull") << " << (" << G << " * q);\n"
       << "    auto P = [&](int slot) -> double { return params[(long long)slot * SB + bb]; };\n\n";
 
     // ---- launch setup: zero staging, constants, terms
-    o << "    for (int i = g; i < " << (nStage + 1) * G << "; i += 16) ST[i] = 0.0;\n"
-      << "    for (int i = g; i < " << nT1 << "; i += 16) TT[i] = 0.0;\n"
-      << "    for (int i = g; i < " << 2 * nT1 << "; i += 16) TS[i] = 0.0;\n"
-      << "    for (int i = g; i < " << ir.n_params << "; i += 16) PL[i] = P(i);\n"
-      << "    if (g == 0) { XS[" << NP << "] = 0.0; XP[" << NP << "] = 0.0; }\n"
+    if (!quad)
+        o << "    for (int i = g; i < " << (nStage + 1) * G << "; i += " << GS << ") ST[i] = 0.0;\n";
+    o << "    for (int i = g; i < " << nT1 << "; i += " << GS << ") TT[i] = 0.0;\n";
+    if (!quad)
+        o << "    for (int i = g; i < " << 2 * nT1 << "; i += " << GS << ") TS[i] = 0.0;\n"
+          << "    for (int i = g; i < " << ir.n_params << "; i += " << GS << ") PL[i] = P(i);\n";
+    o
+      << "    if (g == 0) { XS[" << NP << "] = 0.0; " << (quad ? std::string() : "XP[" + std::to_string(NP) + "] = 0.0; ") << "}\n"
       << "    grp_sync();\n"
       << "    bool badL = false;\n"
-      << "    for (int e = g; e < " << ir.n_elems << "; e += 16) {          // terms constant over the launch (tanalisis.cpp:59-80,294-341)\n"
+      << "    for (int e = g; e < " << ir.n_elems << "; e += " << GS << ") {          // terms constant over the launch (tanalisis.cpp:59-80,294-341)\n"
       << "        const int kind = grp_kind[e], s = grp_slot[e], tb = grp_tbase[e];\n"
       << "        if (kind == " << CSIM_R << ") { const double R = P(s); TT[tb + " << T_R_G << "] = (R == 0.0) ? 0.0 : 1.0 / R; }\n"
       << "        else if (kind == " << CSIM_C << ") { const double C = P(s); TT[tb + " << T_C_GC << "] = (C > 0.0 && dt > 0.0) ? C / dt : 0.0; }\n"
@@ -350,10 +415,23 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     for (int r = 0; r < srcRounds; ++r)
         o << "    const int se" << r << " = grp_src[" << r * G << " + g];       // source evaluated by this lane in round " << r << " (-1: none)\n"
           << "    const int sq" << r << " = se" << r << " >= 0 ? se" << r << " : 0;\n"
-          << "    const int ssl" << r << " = grp_slot[sq" << r << "], stb" << r << " = grp_tbase[sq" << r << "], swv" << r << " = grp_wave[sq" << r
+          << "    const int ssl" << r << " = grp_slot[sq" << r << "], stb" << r << (quad ? " = grp_srcSlot[" + std::to_string(r * G) + " + g]" : " = grp_tbase[sq" + std::to_string(r) + "]") << ", swv" << r << " = grp_wave[sq" << r
           << "], swn" << r << " = grp_waveN[sq" << r << "];\n";
+    if (quad)
+        for (int r = 0; r < srcRounds; ++r)
+            o << "    const int spo" << r << " = grp_srcOff[" << r * G << " + g];\n"
+              << "    if (se" << r << " >= 0) {\n"
+              << "        const int np = (se" << r << " + 1 < " << ir.n_elems << " ? grp_slot[se" << r << " + 1] : " << ir.n_params << ") - ssl" << r << ";\n"
+              << "        for (int i = 0; i < np; ++i) PL[spo" << r << " + i] = P(ssl" << r << " + i);\n"
+              << "    }\n";
     for (int r = 0; r < histRounds; ++r)
         o << "    const int hA" << r << " = grp_hA[" << r * G << " + g], hG" << r << " = grp_hG[" << r * G << " + g];\n";
+    if (quad) {
+        for (int r = 0; r < histRounds; ++r) o << "    const double hc" << r << " = TT[hG" << r << " & 0xFFFF];\n";
+        o << "    grp_sync();        // TT is dead from here on: its place is taken by the per-step terms and the staging rows\n"
+          << "    for (int i = g; i < " << 2 * (zeroSlot + 1) << "; i += " << GS << ") TS[i] = 0.0;\n"
+          << "    for (int i = g; i < " << nStage * G + (gopt.dummyOneCell ? 1 : G) << "; i += " << GS << ") ST[i] = 0.0;\n";
+    }
     {
         int base = 0;
         for (int s = 0; s < S; ++s)
@@ -374,7 +452,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
       << "    long long sdone = (inb && !dead) ? (long long)done[bb] : nSteps;\n"
       << (guard ? "    int nearS = 0;          // step (of this launch) of the group's first near-threshold convergence decision; 0 = none\n" : "")
       << "    if (stepFirst == 0 && sdone == 0 && wave && inb)\n"
-      << "        for (int pq = g; pq < nProbe; pq += 16) wave[((long long)pq) * SB + b] = XS[probeEq[pq]];\n";
+      << "        for (int pq = g; pq < nProbe; pq += " << GS << ") wave[((long long)pq) * SB + b] = XS[probeEq[pq]];\n";
     const bool piped = gopt.pipelineMos != 0 && mosRounds > 0 && nStage > 0;
     // ---- MOSFET evaluation + scatter into the staging rows
     auto emitMos = [&](const std::string& ind) {
@@ -423,13 +501,13 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
       << "        // same array): the history operands and the first iteration's MOSFET inputs fly while the sources are\n"
       << "        // evaluated, the right-hand-side terms in one batch after the writes.\n";
     for (int r = 0; r < histRounds; ++r)
-        o << "        const double hc" << r << " = TT[hG" << r << " & 0xFFFF], hp" << r << " = XP[hA" << r << " & 0xFF], hq" << r << " = XP[hA" << r << " >> 8];\n";
+        o << "        const double " << (quad ? std::string() : "hc" + std::to_string(r) + " = TT[hG" + std::to_string(r) + " & 0xFFFF], ") << "hp" << r << " = " << (quad ? "XH" : "XP") << "[hA" << r << " & 0xFF], hq" << r << " = " << (quad ? "XH" : "XP") << "[hA" << r << " >> 8];\n";
     if (!piped)
         for (int r = 0; r < mosRounds; ++r)
             o << "        double vd" << r << " = XS[mD" << r << "], vg" << r << " = XS[mG" << r << "], vs" << r << " = XS[mS" << r << "];\n";
     for (int r = 0; r < srcRounds; ++r)
         o << "        if (se" << r << " >= 0) {\n"
-          << "            const double v = grp_source_tran([&](int i) { return PL[ssl" << r << " + i]; }, swv" << r << ", swn" << r << ", tNow, " << lit(K.pi) << ");\n"
+          << "            const double v = grp_source_tran([&](int i) { return PL[" << (quad ? "spo" : "ssl") << r << " + i]; }, swv" << r << ", swn" << r << ", tNow, " << lit(K.pi) << ");\n"
           << "            TS[2 * stb" << r << "] = v; TS[2 * stb" << r << " + 1] = -v;\n"
           << "        }\n";
     for (int r = 0; r < histRounds; ++r)
@@ -538,7 +616,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
             absP = lit(std::fabs(col.pivotValue));
             rinv[static_cast<std::size_t>(k)] = lit(1.0 / col.pivotValue);
         } else {
-            o << in << "const double pb" << k << " = grp_bc<" << lk << ">(" << ak << ");\n";
+            o << in << "const double pb" << k << " = " << BC << lk << ">(" << ak << ");\n";
             absP = "fabs(pb" + std::to_string(k) + ")";
             o << in << "pmin = fmin(pmin, " << absP << ");\n";          // tiny pivot (solver.hpp:58-61), tested once per solve
         }
@@ -596,7 +674,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
             std::string ub;
             if (u.isConst) ub = lit(u.c);
             else {
-                o << in << "const double u" << k << "_" << u.j << " = grp_bc<" << lk << ">(a_" << sk << "_" << u.j << ");\n";
+                o << in << "const double u" << k << "_" << u.j << " = " << BC << lk << ">(a_" << sk << "_" << u.j << ");\n";
                 ub = "u" + std::to_string(k) + "_" + std::to_string(u.j);
             }
             for (int s : col.lSlots) {
@@ -622,7 +700,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
         o << in << "const double xt" << j << " = a_" << sj << "_" << N << " * " << rinv[static_cast<std::size_t>(j)] << ";\n";
         if (home)
             o << in << xname << sj << " = (g == " << lj << ") ? xt" << j << " : " << xname << sj << ";      // lane " << lj << " keeps its own solution entry\n";
-        o << in << "const double xb" << j << " = grp_bc<" << lj << ">(xt" << j << ");\n";
+        o << in << "const double xb" << j << " = " << BC << lj << ">(xt" << j << ");\n";
         if (!home)
             o << in << xname << j / G << " = (g == " << j % G << ") ? xb" << j << " : " << xname << j / G << ";\n";
         for (int s : pl.backSlots[static_cast<std::size_t>(j)])
@@ -661,7 +739,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     o << in << "double ss = 0.0;\n";
     for (int s = 0; s < S; ++s)
         o << in << "{ const double d = xn" << s << " - xo" << s << "; ss += d * d; }\n";
-    o << in << "ss = grp_sum16(ss);\n"
+    o << in << (quad ? "ss = grp_sum4(ss);\n" : "ss = grp_sum16(ss);\n")
       // With the guard on, the pass decides on the SQUARED norm: sqrt is monotonic, so `ss < tol^2` and the reference's
       // `sqrt(ss) < tol` (tanalisis.cpp:366-369) can differ only when ss is within a few ulp of tol^2 -- far inside the
       // guard band, where the faithful kernel (which takes the root) has the last word.  Saves the 22-instruction
@@ -724,7 +802,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
       << "            if (stepIters && g == 0) stepIters[(s - 1) * SB + b] = it;\n"
       << "            if (wave && ophase == 0) {\n"
       << "                const long long row = orow;\n"
-      << "                for (int pq = g; pq < nProbe; pq += 16) wave[(row * nProbe + pq) * SB + b] = XS[probeEq[pq]];\n"
+      << "                for (int pq = g; pq < nProbe; pq += " << GS << ") wave[(row * nProbe + pq) * SB + b] = XS[probeEq[pq]];\n"
       << "            }\n"
       << "            sdone = s;\n"
       << "        }\n"
@@ -743,6 +821,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
       << "        }\n"
       << "    }\n"
       << "}\n\n";
+    if (quad) o << "}   // namespace csim_q4\n\n";
     return o.str();
 }
 

@@ -143,6 +143,8 @@ void adoptScheduleTable(csim_engine* eng, void* lib)
     typedef int (*LanesFn)(void);
     LanesFn lanesFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_group_lanes"));
     eng->schedGroupLanes = lanesFn ? lanesFn() : 0;
+    LanesFn quadFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_group4_lanes"));
+    eng->schedQuadLanes = quadFn ? quadFn() : 0;
     LanesFn linFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_linear_lanes"));
     eng->schedLinearLanes = linFn ? linFn() : 0;
     LanesFn faithFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_has_faithful"));
@@ -194,7 +196,7 @@ EngineConfig configFromEnvironment()
     c.jitDcForce = std::getenv("CSIM_JIT_DC_FORCE") != nullptr;
     c.hybridSync = envInt("CSIM_HYBRID_SYNC", 1) != 0;
     c.dcFast = envInt("CSIM_DC_FAST", 0) != 0;
-    if (c.lanesPerInstance != 0 && c.lanesPerInstance != 1 && c.lanesPerInstance != 16) c.lanesPerInstance = 0;
+    if (c.lanesPerInstance != 0 && c.lanesPerInstance != 1 && c.lanesPerInstance != 4 && c.lanesPerInstance != 16) c.lanesPerInstance = 0;
     return c;
 }
 
@@ -337,7 +339,11 @@ int csim_engine_set_option(csim_engine* eng, const char* key, const char* value)
     else if (k == "hybrid_steps") c.hybridSteps = std::max(1, iv);
     else if (k == "sched_variant") c.schedVariant = iv;
     else if (k == "lanes_per_instance") {
-        if (iv != 0 && iv != 1 && iv != 16) { setError("lanes_per_instance must be 0 (auto), 1 or 16"); return CSIM_ERR_ARG; }
+        if (iv != 0 && iv != 1 && iv != 4 && iv != 16) { setError("lanes_per_instance must be 0 (auto), 1, 4 or 16"); return CSIM_ERR_ARG; }
+        if (iv == 4 && eng->schedLaunch && eng->schedQuadLanes != 4) {
+            setError("lanes_per_instance=4: the loaded kernel library has no four-lanes-per-instance kernel");
+            return CSIM_ERR_ARG;
+        }
         if (iv == 16 && eng->schedLaunch && eng->schedGroupLanes != 16) {
             setError("lanes_per_instance=16: the loaded kernel library has no sixteen-lanes-per-instance kernel");
             return CSIM_ERR_UNSUPPORTED;
@@ -397,7 +403,8 @@ static int schedVariantFor(const csim_engine* eng, int32_t B)
     // (a library without the sixteen-lane kernel -- a linear circuit's, or one loaded after the option was set --
     // runs its lane-per-instance kernel whatever the option says)
     if (eng->cfg.lanesPerInstance == 16 && eng->schedGroupLanes == 16) return 16;
-    if (eng->cfg.lanesPerInstance == 1 || eng->cfg.lanesPerInstance == 16) return 0;
+    if (eng->cfg.lanesPerInstance == 4 && eng->schedQuadLanes == 4) return 4;
+    if (eng->cfg.lanesPerInstance != 0) return 0;
     // auto: sixteen lanes per instance while the batch is too small to give every SIMD a wave of 64
     // instances.  Measured on dbmixer (gpurun_out/sw9): 16 lanes 2.4-2.5e9 NR-iter*inst/s from B = 4096 up (one
     // wave per SIMD, further instances run as further rounds), one lane 8.6e8 at B = 4096 growing linearly --
@@ -410,7 +417,8 @@ extern "C" int csim_engine_lanes_for_batch(const csim_engine* eng, int32_t B)
 {
     if (!eng || !eng->schedLaunch || eng->kernelChoice == 1) return 0;
     if (eng->schedLinearLanes) return eng->schedLinearLanes;       // a linear circuit's library has one transient kernel
-    return schedVariantFor(eng, B) == 16 ? 16 : 1;
+    const int v = schedVariantFor(eng, B);
+    return v == 16 ? 16 : (v == 4 ? 4 : 1);
 }
 
 // per-instance hand-over masks, progress counters and flag words of the generated kernels

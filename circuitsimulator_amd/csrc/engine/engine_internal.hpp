@@ -15,7 +15,7 @@ struct EngineConfig {
     int hybridRounds = 4;        // hybrid_rounds  / CSIM_HYBRID_ROUNDS: hand-back rounds per transient call
     int hybridSteps = 64;        // hybrid_steps   / CSIM_HYBRID_STEPS: most steps the general kernel keeps an instance per round
     int schedVariant = 0;        // sched_variant  / CSIM_SCHED_VARIANT: 0 auto, 2 rich, 10+k sweep kernels (tuning aid)
-    int lanesPerInstance = 0;    // lanes_per_instance / CSIM_LANES_PER_INSTANCE: 0 auto (by batch size), 1 or 16
+    int lanesPerInstance = 0;    // lanes_per_instance / CSIM_LANES_PER_INSTANCE: 0 auto (by batch size), 1, 4 or 16
     bool autoJit = false;        // auto_jit       / CSIM_AUTO_JIT: host API specialises a new circuit on first use
     std::string jitDir;          // jit_dir        / CSIM_JIT_DIR (default: private per-user directory, jit.hpp)
     std::string hipcc;           // hipcc          / CSIM_HIPCC
@@ -71,6 +71,7 @@ struct csim_engine {
     int schedWorkCap = 0;                  // instances
     bool schedHasFaithful = false;         // the library carries csim_tran_faithful_kernel (launch variant 3)
     int schedGroupLanes = 0;               // 16 when the library also carries the sixteen-lanes-per-instance kernel
+    int schedQuadLanes = 0;                // 4 when it carries the four-lanes-per-instance kernel too
     int schedLinearLanes = 0;              // linear-circuit library: lanes per instance of its kernel (16 or 1), else 0
     int32_t* dKnownAlts = nullptr;         // [nKnownAlts][N] pivot sequences the loaded kernel carries
     int nKnownAlts = 0;

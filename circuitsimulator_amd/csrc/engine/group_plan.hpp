@@ -120,7 +120,9 @@ std::string groupPreludeSource(const csim_ir& ir);
 
 // the __global__ kernel "csim_tran_group_kernel" + its tables; "" if the circuit does not fit.  One solve
 // body per schedule, tried in order per Newton pass for the groups whose checks failed so far.
+// lanes = 4: the same kernel over DPP quads, "csim_tran_group4_kernel" (16 instances per wavefront; tables in
+// namespace csim_q4).
 std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std::vector<PivotSchedule>& schedules,
-                            const GeneratorOptions& gopt, GroupPlan* planOut);
+                            const GeneratorOptions& gopt, GroupPlan* planOut, int lanes = kGroupLanes);
 
 } // namespace csim
