@@ -151,7 +151,7 @@ uint64_t scheduleHash(const csim_ir& ir, const ScheduleSet& set, const Generator
     mix(static_cast<uint64_t>(gopt.linSrcLds + 17) * 0x165667B19E3779F9ull);
     mix(static_cast<uint64_t>(gopt.dummyOneCell + 19) * 0x85EBCA77C2B2AE63ull);
     mix(static_cast<uint64_t>(gopt.linChainBarrier + 23) * 0x27D4EB2F165667C5ull);
-    if (gopt.group4) mix(static_cast<uint64_t>(gopt.group4 + 29) * 0x9FB21C651E98DF25ull);
+    mix(static_cast<uint64_t>(gopt.group4 + 29) * 0x9FB21C651E98DF25ull);
     for (std::size_t a = 1; a < set.alts.size(); ++a) {
         h ^= 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
         for (int p : set.alts[a].pivotPos) { h ^= static_cast<uint64_t>(p + 1); h *= 1099511628211ull; }

@@ -88,7 +88,8 @@ struct GeneratorOptions {
                                  // instead of one each: writes to one address do not conflict, sixteen scattered dummies did with the real
                                  // destinations (SQ_LDS_BANK_CONFLICT 3.85e8 -> 2.97e8 per launch, 30.8 % -> 25.6 % of the LDS-active
                                  // cycles; +0.4 % on the bench, same box: gpurun_out/r03v)
-    int group4 = 0;              // 1 = the library also carries the four-lanes-per-instance form of the group kernel (csim_tran_group4_kernel)
+    int group4 = 1;              // 1 = the library also carries the four-lanes-per-instance form of the group kernel (csim_tran_group4_kernel),
+                                 // for circuits of up to 32 unknowns: the batches between the sixteen-lane and the lane-per-instance kernel
     int linChainBarrier = 0;     // linear sixteen-lane kernel: scheduling barrier after each critical link of the forward chain
     int linFactorBlock = 64;     // linear sixteen-lane library: lanes per workgroup of the factor kernel (0 = 16 / 32 / 64 by batch size;
                                  // measured on the N = 257 ladder at B = 8192, same box: 64 -> 3.09 ms per launch, by batch size (16) -> 3.16 ms)
@@ -99,7 +100,7 @@ struct GeneratorOptions {
 };
 
 // bumped whenever the emitted code or the launcher ABI of a generated library changes
-constexpr int kGeneratorRevision = 36;
+constexpr int kGeneratorRevision = 37;
 
 // identifies (topology, constants, schedule); names the generated library
 uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch);

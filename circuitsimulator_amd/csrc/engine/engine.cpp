@@ -396,7 +396,7 @@ static int readFlags(csim_engine* eng, hipStream_t hs, bool* unfinished, bool* t
 }
 
 // which kernel of the generated library a launch of B instances uses (csim_sched_launch's `variant`):
-// 0 = lane per instance, 16 = sixteen lanes per instance, other values = tuning kernels
+// 0 = lane per instance, 16 = sixteen lanes per instance, 4 = four lanes per instance, other values = tuning kernels
 static int schedVariantFor(const csim_engine* eng, int32_t B)
 {
     if (eng->cfg.schedVariant != 0) return eng->cfg.schedVariant;
@@ -410,6 +410,12 @@ static int schedVariantFor(const csim_engine* eng, int32_t B)
     // wave per SIMD, further instances run as further rounds), one lane 8.6e8 at B = 4096 growing linearly --
     // 1.70e9 at 8192, 2.55e9 at 12 288 -- to 1.25e10 at 65 536: they cross near B = 11 400.  Both kernels carry the
     // same set of pivot schedules.
+    // Four lanes per instance (circuits of up to 32 unknowns) sit between the two: 16 instances per wavefront, one
+    // wave per SIMD, so a round of 16 384 instances takes what one wave takes -- on dbmixer 30.6 ms per 1000 steps against
+    // 17.5 ms per round of 4096 for sixteen lanes and 52.4 ms for one lane (gpurun_out/r03q/probe3.log): the best of
+    // the three from 4097 to 16 384 instances (5.83e9 at 16 384, where one lane gives 3.38e9), never beyond (two
+    // rounds take longer than the lane-per-instance kernel's one).
+    if (eng->schedQuadLanes == 4 && B > 4096 && B <= 16384) return 4;
     return (eng->schedGroupLanes == 16 && B <= 11264) ? 16 : 0;
 }
 

@@ -34,8 +34,8 @@
  * Arithmetic.  The general kernels, the "faithful" generated kernels (transient and DC) and the kernels for
  * linear circuits perform the reference's floating-point operations in the reference's order (the device's
  * sin() may differ from glibc's in the last bit).  The FAST generated transient kernels (family "scheduled":
- * one and sixteen lanes per instance) deviate deliberately, inside the 1e-9 bar, NR counts equal: FMA
- * contraction; one refined reciprocal per pivot instead of a division per multiplier; sixteen-lane kernel:
+ * one, four and sixteen lanes per instance) deviate deliberately, inside the 1e-9 bar, NR counts equal: FMA
+ * contraction; one refined reciprocal per pivot instead of a division per multiplier; four-/sixteen-lane kernels:
  * matrix assembled as (step-constant part) + (MOSFET part), back substitution in descending column order, the
  * recorded pivot accepted where a LATER row exceeds it by less than 8 ulp (the reference would swap: the two
  * pivots then agree to 15 digits; include/solver.hpp:48-56), the update norm summed across lanes; convergence
@@ -143,7 +143,7 @@ const char* csim_engine_tran_kernel(const csim_engine* eng);
  * per lane, and the floating-point operations ONE solve on the first schedule executes
  * ("ops_per_solve: fma=.. mul=.. addsub=.. recip=.. cmp=..")                                   */
 const char* csim_engine_sched_info(const csim_engine* eng);
-/* lanes per instance the scheduled transient kernel would use for a batch of B instances (1 or 16;
+/* lanes per instance the scheduled transient kernel would use for a batch of B instances (1, 4 or 16;
  * 0 = the general kernel runs: one 64-lane wavefront per instance).  A linear circuit's library has one
  * transient kernel: 16 (tape and iterate in registers) or 1 (larger circuits), whatever B is.        */
 int  csim_engine_lanes_for_batch(const csim_engine* eng, int32_t B);
@@ -158,7 +158,9 @@ int  csim_engine_set_kernel(csim_engine* eng, int32_t which);
  *                                           kernel per transient call
  *   hybrid_steps  (CSIM_HYBRID_STEPS, 64)   most steps the general kernel keeps an instance per round
  *   lanes_per_instance (CSIM_LANES_PER_INSTANCE, 0)  scheduled transient kernel: 1 = lane per instance,
+ *                                           4 = four lanes per instance (circuits of up to 32 unknowns),
  *                                           16 = sixteen lanes per instance, 0 = chosen by batch size
+ *                                           (<= 4096: 16; up to 16 384: 4; beyond: 1)
  *   sched_variant (CSIM_SCHED_VARIANT, 0)   tuning kernels of a generated library (2 rich, 10+k sweep)
  *   auto_jit (CSIM_AUTO_JIT, off)           csim_tran_batch specialises a new circuit on first use
  *   jit_dir (CSIM_JIT_DIR; default $XDG_CACHE_HOME/csim_jit or /tmp/csim_jit.<uid>)  JIT cache: created

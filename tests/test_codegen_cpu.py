@@ -53,12 +53,32 @@ def test_group_plan_self_test_on_the_shipped_schedules(codegen):
     interpreter on random term values against a dense elimination with the same pivots: csim_codegen
     --selftest-group exits 0 when every schedule agrees to 1e-9 and no all-lane candidate test could see a row it
     must not."""
+    for flag in ("--selftest-group", "--selftest-group4"):          # sixteen and four lanes per instance
+        for name in ("buffer", "dbmixer"):
+            p = subprocess.run([codegen, flag, netlist_path(name + ".sp"), os.path.join(SCHED, name + ".sched")],
+                               capture_output=True, text=True)
+            assert p.returncode == 0, (flag, name, p.stdout[-400:], p.stderr[-400:])
+            assert "group plan self test: worst relative difference" in p.stdout
+        assert p.stdout.count("group plan alt") >= 1
+
+
+def test_generated_library_carries_the_four_lane_kernel(codegen, tmp_path):
+    """Circuits of up to 32 unknowns get the four-lanes-per-instance form of the group kernel too (16 instances
+    per wavefront, tables in their own namespace, csim_sched_launch variant 4); its LDS image per instance is padded
+    to 4 (mod 8) doubles so that the instances of a wavefront start on different banks."""
     for name in ("buffer", "dbmixer"):
-        p = subprocess.run([codegen, "--selftest-group", netlist_path(name + ".sp"), os.path.join(SCHED, name + ".sched")],
-                           capture_output=True, text=True)
-        assert p.returncode == 0, (name, p.stdout[-400:], p.stderr[-400:])
-        assert "group plan self test: worst relative difference" in p.stdout
-    assert p.stdout.count("group plan alt") >= 1
+        text = open(os.path.join(SCHED, name + ".sched")).read()
+        p, src = _run(codegen, netlist_path(name + ".sp"), text, tmp_path)
+        assert p.returncode == 0, p.stderr
+        assert "csim_tran_group4_kernel(" in src and "namespace csim_q4 {" in src
+        assert "csim_sched_group4_lanes(void) { return 4; }" in src and "if (variant == 4) {" in src
+        per_inst = int(src.split("__shared__ double lds[16 * ")[1].split("]")[0])
+        assert per_inst % 8 == 4 and per_inst * 16 * 8 <= 40 * 1024, per_inst       # four workgroups per CU
+    p = subprocess.run([codegen, "--opt", "group4=0", netlist_path("dbmixer.sp"), os.path.join(SCHED, "dbmixer.sched"),
+                        str(tmp_path / "no4.hip")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    src = (tmp_path / "no4.hip").read_text()
+    assert "csim_tran_group4_kernel(" not in src and "csim_sched_group4_lanes(void) { return 0; }" in src
 
 
 def test_generator_options_are_part_of_the_library_identity(codegen, tmp_path):

@@ -137,9 +137,9 @@ def test_buffer_10k_steps_batch1_config(engines, torch_mod, anchors):
     assert rel_err(r["wave"][:, :, 0], o["rows"][:, 1:]).max() < TOL
 
 
-@pytest.mark.parametrize("lanes", [1, 16])
+@pytest.mark.parametrize("lanes", [1, 4, 16])
 def test_dbmixer_mc_transient_vs_oracle(engines, torch_mod, lanes):
-    """Both generated transient kernels (one lane per instance; sixteen lanes per instance) against the oracle."""
+    """The generated transient kernels (one lane per instance; four and sixteen lanes per instance) against the oracle."""
     nl, eng = engines["dbmixer"]
     B, steps = 64, 1500
     params = eng.mc_params(12345, 0.05, 0, B)
@@ -233,26 +233,27 @@ def test_group_kernel_ragged_batches_chunks_and_probes(engines, torch_mod):
     fill the last wave, launches cut into chunks, probe rows -- all must equal the lane-per-instance
     kernel (same NR counts per step, states within 1e-9) and, for the first and last instance, the oracle."""
     nl, eng = engines["dbmixer"]
-    assert "group16" in eng.sched_info["text"]
-    for B in (1, 3, 5, 67, 256):
+    assert "group16" in eng.sched_info["text"] and "group4" in eng.sched_info["text"]
+    for B in (1, 3, 5, 17, 67, 256):
         params = eng.mc_params(777, 0.05, 0, B)
         eng.set_option("lanes_per_instance", 1)
         ref = _run_tran(torch_mod, eng, params, 240, nl.tstep, probes=[1, 2, 30], stride=40, want_step_iters=True)
-        eng.set_option("lanes_per_instance", 16)
-        try:
-            got = _run_tran(torch_mod, eng, params, 240, nl.tstep, probes=[1, 2, 30], stride=40, want_step_iters=True,
-                            chunks=[1, 99, 140])
-        finally:
-            eng.set_option("lanes_per_instance", 0)
-        assert np.array_equal(got["step_iters"], ref["step_iters"]), B
-        assert np.array_equal(got["status"], ref["status"]) and not (got["status"] & 0x27).any(), B
-        assert rel_err(got["x"].T, ref["x"].T).max() < TOL, B
-        assert rel_err(got["wave"].reshape(-1, B).T, ref["wave"].reshape(-1, B).T).max() < TOL, B
         ph = params.cpu().numpy()
-        for b in {0, B - 1}:
-            o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstep * 240, want_step_iters=True)
-            assert np.array_equal(got["step_iters"][:, b], o["step_iters"]), (B, b)
-            assert rel_err(got["x"][:, b], o["x_final"]).max() < TOL, (B, b)
+        orc = {b: _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstep * 240, want_step_iters=True) for b in {0, B - 1}}
+        for lanes in (16, 4):            # 4 resp. 16 instances per wavefront
+            eng.set_option("lanes_per_instance", lanes)
+            try:
+                got = _run_tran(torch_mod, eng, params, 240, nl.tstep, probes=[1, 2, 30], stride=40, want_step_iters=True,
+                                chunks=[1, 99, 140])
+            finally:
+                eng.set_option("lanes_per_instance", 0)
+            assert np.array_equal(got["step_iters"], ref["step_iters"]), (B, lanes)
+            assert np.array_equal(got["status"], ref["status"]) and not (got["status"] & 0x27).any(), (B, lanes)
+            assert rel_err(got["x"].T, ref["x"].T).max() < TOL, (B, lanes)
+            assert rel_err(got["wave"].reshape(-1, B).T, ref["wave"].reshape(-1, B).T).max() < TOL, (B, lanes)
+            for b, o in orc.items():
+                assert np.array_equal(got["step_iters"][:, b], o["step_iters"]), (B, b, lanes)
+                assert rel_err(got["x"][:, b], o["x_final"]).max() < TOL, (B, b, lanes)
 
 
 def _amplifier_line(stages):
@@ -334,7 +335,7 @@ def test_group_kernel_carries_every_recorded_schedule(engines, torch_mod):
     eng.set_kernel("auto")
     assert eng.lanes_for_batch(B) == 16
     runs = {}
-    for lanes in (1, 16):
+    for lanes in (1, 4, 16):
         eng.set_option("lanes_per_instance", lanes)
         try:
             runs[lanes] = _run_tran(torch_mod, eng, params, 300, nl.tstep, want_step_iters=True, chunks=[150, 150])
@@ -344,8 +345,8 @@ def test_group_kernel_carries_every_recorded_schedule(engines, torch_mod):
         assert np.array_equal(runs[lanes]["status"] & NOFB, slow["status"])
         assert rel_err(runs[lanes]["x"].T, slow["x"].T).max() < TOL
     flagged = {lanes: int(((r["status"] & FALLBACK) != 0).sum()) for lanes, r in runs.items()}
-    assert flagged[16] <= flagged[1], flagged
-    assert flagged[16] < B // 4, flagged          # the alternatives are in use, not handed over
+    assert flagged[16] <= flagged[1] and flagged[4] <= flagged[1], flagged
+    assert flagged[16] < B // 4 and flagged[4] < B // 4, flagged          # the alternatives are in use, not handed over
     # one instance against the oracle at a step where the first schedule holds throughout
     eng.set_option("lanes_per_instance", 16)
     try:
@@ -398,8 +399,8 @@ def test_shipped_netlists_have_scheduled_kernels(engines):
     for name in ("buffer", "dbmixer"):
         nl, eng = engines[name]
         assert eng.tran_kernel == "scheduled", name
-        # sixteen lanes per instance up to the measured crossing with the lane-per-instance kernel
-        assert eng.lanes_for_batch(1) == 16 and eng.lanes_for_batch(11264) == 16 and eng.lanes_for_batch(11265) == 1
+        # 16 lanes per instance up to one round of the chip (4096), four up to ITS one round (16 384), one beyond
+        assert [eng.lanes_for_batch(b) for b in (1, 4096, 4097, 16384, 16385, 65536)] == [16, 16, 4, 4, 1, 1]
         assert len(eng.loaded_schedules()[0]) == {"buffer": 10, "dbmixer": 1}[name]
 
 
@@ -1124,6 +1125,15 @@ def test_pulse_pwl_sources_general_and_scheduled(torch_mod, tmp_path, monkeypatc
     assert rel_err(fast["wave"].transpose(2, 0, 1).reshape(-1, len(probes)),
                    slow["wave"].transpose(2, 0, 1).reshape(-1, len(probes))).max() < TOL
     assert ((fast["status"] & FALLBACK) != 0).sum() < B // 2
+    for lanes in (4, 1):                 # (the run above: sixteen lanes per instance; four keep the sources' parameters packed)
+        eng.set_option("lanes_per_instance", lanes)
+        assert eng.lanes_for_batch(B) == lanes
+        other = _run_tran(torch_mod, eng, params, steps, nl.tstep, probes=probes, want_step_iters=True)
+        assert np.array_equal(other["step_iters"], slow["step_iters"]), lanes
+        assert np.array_equal(other["status"] & NOFB, slow["status"]), lanes
+        assert rel_err(other["wave"].transpose(2, 0, 1).reshape(-1, len(probes)),
+                       slow["wave"].transpose(2, 0, 1).reshape(-1, len(probes))).max() < TOL, lanes
+    eng.set_option("lanes_per_instance", 0)
     # host API, nominal instance: every CSV column
     wave, xf, it, st = eng.tran_host(B=1, probes=list(range(nl.n_unknowns)))
     o = orc.tran(nl.ir_ptr, nl.n_unknowns, nl.nominal_params, 0, nl.tstep, nl.tstop)
@@ -1294,6 +1304,12 @@ def test_random_netlists_generated_kernels(torch_mod, tmp_path, monkeypatch):
         assert np.array_equal(fast["step_iters"], slow["step_iters"]), seed
         assert np.array_equal(fast["status"] & NOFB, slow["status"]), seed
         assert rel_err(fast["x"].T, slow["x"].T).max() < TOL, seed
+        assert "group4" in eng.sched_info["text"], seed
+        eng.set_option("lanes_per_instance", 4)
+        quad = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+        assert np.array_equal(quad["step_iters"], slow["step_iters"]), seed
+        assert np.array_equal(quad["status"] & NOFB, slow["status"]), seed
+        assert rel_err(quad["x"].T, slow["x"].T).max() < TOL, seed
         n_dc_kernels += int(((fast["status"] & FALLBACK_DC) != 0).any())
     print("random netlists: %d of 6 circuits had DC instances replayed by the general kernel" % n_dc_kernels)
 

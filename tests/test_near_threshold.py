@@ -91,7 +91,7 @@ def test_faithful_dc_kernel_is_bitwise_the_general_kernel(torch_mod, dbmixer_nl)
     assert rel_err(xs.cpu().numpy().T, xg.cpu().numpy().T).max() < TOL
 
 
-@pytest.mark.parametrize("lanes", [16, 1])
+@pytest.mark.parametrize("lanes", [16, 4, 1])
 def test_near_threshold_decisions_are_verified_and_rolled_back(torch_mod, dbmixer_nl, tmp_path, monkeypatch, lanes):
     """dbmixer.sp kernels generated with a guard band of 15 % (the shipped band is 2e-8: its events are too rare to
     test -- and, the Monte-Carlo instances' trajectories being near copies of each other, so were those of a 2 %

@@ -29,6 +29,7 @@ def main():
     bad = 0
     n_fb = 0
     n_ver = 0
+    n_quad = 0
     for seed in range(a.first, a.first + a.count):
         rs = np.random.RandomState(seed)
         nl = Netlist.from_text(t._random_netlist(rs, rs.randint(3, 25), rs.randint(0, 8)))
@@ -58,13 +59,28 @@ def main():
                 if e >= t.TOL:
                     problems.append("x deviates %.2e%s" % (e, tag))
             n_fb += int(((fast["status"] & 0xA0) != 0).sum())
+            n_fb += int(((fast["status"] & 0xA0) != 0).sum())
+        eng.set_option("dc_fast", 0)
+        if "group4" in eng.sched_info["text"]:           # the four-lanes-per-instance transient kernel
+            eng.set_option("lanes_per_instance", 4)
+            quad = t._run_tran(torch, eng, params, steps, nl.tstep, want_step_iters=True)
+            if not np.array_equal(quad["step_iters"][:, clean], slow["step_iters"][:, clean]):
+                problems.append("tran iters (4 lanes)")
+            if not np.array_equal((quad["status"] & t.NOFB)[clean], slow["status"][clean]):
+                problems.append("status (4 lanes)")
+            if clean.any():
+                e = t.rel_err(quad["x"].T[clean], slow["x"].T[clean]).max()
+                if e >= t.TOL:
+                    problems.append("x deviates %.2e (4 lanes)" % e)
+            n_quad += 1
         n_ver += eng.stat("near_verified")
         if problems:
             bad += 1
             print("seed %d N=%d (%d clean of %d): %s" % (seed, nl.n_unknowns, int(clean.sum()), B, "; ".join(problems)), flush=True)
         eng.close()
     print("fuzz: %d circuits (each with the faithful and with the fast DC kernel), %d with mismatches, %d instance runs "
-          "replayed by the general kernels, %d near-threshold decisions verified" % (a.count, bad, n_fb, n_ver))
+          "replayed by the general kernels, %d near-threshold decisions verified; %d circuits also on four lanes per instance"
+          % (a.count, bad, n_fb, n_ver, n_quad))
     sys.exit(1 if bad else 0)
 
 
