@@ -200,7 +200,7 @@ def main():
     ap.add_argument("--tsteps", type=int, default=6000,
                     help="time steps per bench step (one csim_tran_batch_dev call); 6000 x (5 + 20) steps = three times "
                          "the netlist's 50 000-step run (~2 s of timed GPU work at B = 4096 with 20 timed steps)")
-    ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 16],
+    ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 4, 16],
                     help="scheduled kernel: lanes per instance (0 = the engine picks by batch size)")
     ap.add_argument("--dump-gathered", default="",
                     help="rank 0 writes the gathered probe voltages and per-rank NR totals to this .npz (tests)")
@@ -228,6 +228,8 @@ def main():
                     help="engine option hybrid_sync=0: the transient calls only enqueue, the host never waits inside them")
     ap.add_argument("--large-batch", type=int, default=65536,
                     help="also time this many instances per GPU (one wave per SIMD needs >= 65536); 0 = skip")
+    ap.add_argument("--mid-batch", type=int, default=16384,
+                    help="also time this many instances per GPU (the four-lanes-per-instance kernel's range); 0 = skip")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # started bare: be the launcher (no GPU call in this process)
@@ -353,9 +355,7 @@ def main():
     gather_ms = (time.perf_counter() - t0) * 1e3
 
     # ---- second leg: a batch that gives every SIMD a wave (same circuit, same kernels) ------
-    large = None
-    if args.large_batch and args.large_batch != B:
-        BL = args.large_batch
+    def second_leg(BL):
         pl = eng.mc_params(args.seed, args.sigma, rank * BL, BL)
         xl, _, stl = eng.dc(pl)
         itl = torch.zeros(BL, dtype=torch.int64, device=dev)
@@ -374,10 +374,12 @@ def main():
         shard.barrier()
         wl = shard.all_reduce_max(time.perf_counter() - t0, device=dev)
         il = shard.all_reduce_sum_int(int((itl - before).sum().item()), device=dev)
-        large = {"batch_per_gpu": BL, "value": il / wl, "steps": nl_steps,
-                 "kernel_avg_ms": e0.elapsed_time(e1) / nl_steps,
-                 "flagged_instances": int((stl & 0xA7).ne(0).sum().item())}
-        del pl, xl, itl, stl
+        return {"batch_per_gpu": BL, "value": il / wl, "steps": nl_steps,
+                "kernel_avg_ms": e0.elapsed_time(e1) / nl_steps,
+                "flagged_instances": int((stl & 0xA7).ne(0).sum().item())}
+
+    mid = second_leg(args.mid_batch) if args.mid_batch and args.mid_batch != B else None
+    large = second_leg(args.large_batch) if args.large_batch and args.large_batch != B else None
 
     if args.dump_gathered and rank == 0:
         np.savez(args.dump_gathered, gathered=all_v.cpu().numpy(), total_iters=np.int64(total_iters))
@@ -462,7 +464,9 @@ def main():
             "result_gather_ms": gather_ms,
             "gathered_shape": list(all_v.shape),
         }
-        if large is not None:
+        for key, large in (("mid_batch", mid), ("large_batch", large)):
+            if large is None:
+                continue
             lf = large["value"] * abytes / 1e9 / HBM_PEAK_GBS
             large["roofline_frac"] = lf
             large["roofline_artefact"] = lf > 1.0
@@ -472,7 +476,7 @@ def main():
             if kernel == "scheduled":
                 large["roofline_valu"] = valu_roof(large["value"] / world, profiled_counters(nl, lkey, large["batch_per_gpu"]),
                                                    large["batch_per_gpu"], ll, flops_exec)
-            rec["large_batch"] = large
+            rec[key] = large
         if world == 1 and not args.no_cpu:
             # CPU baseline: the oracle (port of the reference algorithm), 1 thread,
             # on the first instances of the same parameter table
