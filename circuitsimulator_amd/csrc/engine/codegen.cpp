@@ -1177,6 +1177,8 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "extern \"C\" int csim_sched_group_lanes(void) { return " << (haveGroup ? 16 : 0) << "; }\n"
         << "// 4 when this library also carries csim_tran_group4_kernel (four lanes per instance; csim_sched_launch variant 4)\n"
         << "extern \"C\" int csim_sched_group4_lanes(void) { return " << (haveQuad ? 4 : 0) << "; }\n"
+        << "// instances of that kernel one CU holds at a time: 16 per workgroup, one wave per SIMD, 160 KB of LDS\n"
+        << "extern \"C\" int csim_sched_group4_per_cu(void) { return " << (haveQuad ? 16 * std::min(4, (160 * 1024) / (quadPlan.ldsDoubles * 16 * 8)) : 0) << "; }\n"
         << "// lanes per instance of the linear-circuit kernel: 16 (registers), 1 (LDS + streamed tape), 0 (not a linear circuit)\n"
         << "extern \"C\" int csim_sched_linear_lanes(void) { return " << (haveLinear16 ? 16 : (haveLinear ? 1 : 0)) << "; }\n";
     src << ""

@@ -324,7 +324,8 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
         while (instDoubles % 8 != 4) ++instDoubles;
     }
     while (gopt.ldsPad && instDoubles % 32 != 16) ++instDoubles;
-    if (instDoubles * 8 * perWave > 150 * 1024) return std::string();  // one CU's LDS (a workgroup of four instances must fit)
+    if (instDoubles * 8 * perWave > 150 * 1024) return std::string();
+    if (planOut) planOut->ldsDoubles = instDoubles;  // one CU's LDS (a workgroup of four instances must fit)
 
 
     o << (quad ? "\n// One DPP quad of 4 lanes = one circuit instance, 16 instances per wavefront (group_plan.hpp).\n"

@@ -145,6 +145,8 @@ void adoptScheduleTable(csim_engine* eng, void* lib)
     eng->schedGroupLanes = lanesFn ? lanesFn() : 0;
     LanesFn quadFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_group4_lanes"));
     eng->schedQuadLanes = quadFn ? quadFn() : 0;
+    LanesFn quadCuFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_group4_per_cu"));
+    eng->schedQuadRound = (eng->schedQuadLanes == 4 && quadCuFn) ? quadCuFn() * eng->numCUs : 0;
     LanesFn linFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_linear_lanes"));
     eng->schedLinearLanes = linFn ? linFn() : 0;
     LanesFn faithFn = reinterpret_cast<LanesFn>(dlsym(lib, "csim_sched_has_faithful"));
@@ -252,6 +254,7 @@ int csim_engine_create(const csim_netlist* nl, int32_t device, csim_engine** out
 
     auto* eng = new csim_engine();
     eng->device = device;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) eng->numCUs = cus; }
     eng->cfg = configFromEnvironment();
     eng->cir = nl->cir;
     eng->cir.view();
@@ -415,8 +418,11 @@ static int schedVariantFor(const csim_engine* eng, int32_t B)
     // 17.5 ms per round of 4096 for sixteen lanes and 52.4 ms for one lane (gpurun_out/r03q/probe3.log): the best of
     // the three from 4097 to 16 384 instances (5.83e9 at 16 384, where one lane gives 3.38e9), never beyond (two
     // rounds take longer than the lane-per-instance kernel's one).
-    if (eng->schedQuadLanes == 4 && B > 4096 && B <= 16384) return 4;
-    return (eng->schedGroupLanes == 16 && B <= 11264) ? 16 : 0;
+    // In general: beyond one round of the sixteen-lane kernel (4 instances x 4 SIMDs per CU) and up to one round of the
+    // four-lane kernel -- 64 instances per CU when four of its workgroups fit a CU's LDS, fewer otherwise (the library
+    // says: csim_sched_group4_per_cu).
+    if (eng->schedQuadLanes == 4 && B > 16 * eng->numCUs && B <= eng->schedQuadRound) return 4;
+    return (eng->schedGroupLanes == 16 && B <= 44 * eng->numCUs) ? 16 : 0;
 }
 
 extern "C" int csim_engine_lanes_for_batch(const csim_engine* eng, int32_t B)

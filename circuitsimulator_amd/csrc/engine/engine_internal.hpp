@@ -72,6 +72,8 @@ struct csim_engine {
     bool schedHasFaithful = false;         // the library carries csim_tran_faithful_kernel (launch variant 3)
     int schedGroupLanes = 0;               // 16 when the library also carries the sixteen-lanes-per-instance kernel
     int schedQuadLanes = 0;                // 4 when it carries the four-lanes-per-instance kernel too
+    int schedQuadRound = 0;                // instances that kernel holds on this device at a time (one wave per SIMD)
+    int numCUs = 256;                      // compute units of the device (MI355X: 256)
     int schedLinearLanes = 0;              // linear-circuit library: lanes per instance of its kernel (16 or 1), else 0
     int32_t* dKnownAlts = nullptr;         // [nKnownAlts][N] pivot sequences the loaded kernel carries
     int nKnownAlts = 0;

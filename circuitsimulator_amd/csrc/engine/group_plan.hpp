@@ -46,7 +46,8 @@ constexpr int kGroupLanes = 16;
 
 struct GroupPlan {
     int N = 0, S = 0;                        // unknowns, slots per lane = ceil(N / G)
-    int G = kGroupLanes;                     // lanes per instance: 16 (one DPP row) or 4 (one quad; 16 instances per wavefront)
+    int G = kGroupLanes;
+    int ldsDoubles = 0;                    // LDS image of one instance in the emitted kernel (set by emitGroupKernel)                     // lanes per instance: 16 (one DPP row) or 4 (one quad; 16 instances per wavefront)
     std::vector<int> finalPos;               // original row -> pivot position
     std::vector<int> rowAtPos;               // pivot position -> original row
 

@@ -74,6 +74,7 @@ def test_generated_library_carries_the_four_lane_kernel(codegen, tmp_path):
         assert "csim_sched_group4_lanes(void) { return 4; }" in src and "if (variant == 4) {" in src
         per_inst = int(src.split("__shared__ double lds[16 * ")[1].split("]")[0])
         assert per_inst % 8 == 4 and per_inst * 16 * 8 <= 40 * 1024, per_inst       # four workgroups per CU
+        assert "csim_sched_group4_per_cu(void) { return 64; }" in src          # ... which the engine's choice of kernel relies on
     p = subprocess.run([codegen, "--opt", "group4=0", netlist_path("dbmixer.sp"), os.path.join(SCHED, "dbmixer.sched"),
                         str(tmp_path / "no4.hip")], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr

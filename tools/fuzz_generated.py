@@ -78,6 +78,8 @@ def main():
             bad += 1
             print("seed %d N=%d (%d clean of %d): %s" % (seed, nl.n_unknowns, int(clean.sum()), B, "; ".join(problems)), flush=True)
         eng.close()
+        if (seed - a.first) % 10 == 9:
+            print("  ... %d of %d circuits, %d with mismatches so far" % (seed - a.first + 1, a.count, bad), flush=True)
     print("fuzz: %d circuits (each with the faithful and with the fast DC kernel), %d with mismatches, %d instance runs "
           "replayed by the general kernels, %d near-threshold decisions verified; %d circuits also on four lanes per instance"
           % (a.count, bad, n_fb, n_ver, n_quad))
