@@ -122,6 +122,7 @@ bool GeneratorOptions::set(const std::string& keyval)
     if (key == "lin_factor_block") { linFactorBlock = std::atoi(val.c_str()); return linFactorBlock == 0 || linFactorBlock == 16 || linFactorBlock == 32 || linFactorBlock == 64; }
     if (key == "lin_src_lds") { linSrcLds = std::atoi(val.c_str()) != 0 ? 1 : 0; return true; }
     if (key == "dummy_one_cell") { dummyOneCell = std::atoi(val.c_str()) != 0 ? 1 : 0; return true; }
+    if (key == "place_search") { placeSearch = std::atoi(val.c_str()) & 3; return true; }
     if (key == "group4") { group4 = std::atoi(val.c_str()) != 0 ? 1 : 0; return true; }
     if (key == "lin_chain_barrier") { linChainBarrier = std::atoi(val.c_str()) != 0 ? 1 : 0; return true; }
     if (key == "sweep") {
@@ -152,6 +153,7 @@ uint64_t scheduleHash(const csim_ir& ir, const ScheduleSet& set, const Generator
     mix(static_cast<uint64_t>(gopt.dummyOneCell + 19) * 0x85EBCA77C2B2AE63ull);
     mix(static_cast<uint64_t>(gopt.linChainBarrier + 23) * 0x27D4EB2F165667C5ull);
     mix(static_cast<uint64_t>(gopt.group4 + 29) * 0x9FB21C651E98DF25ull);
+    mix(static_cast<uint64_t>(gopt.placeSearch + 31) * 0xD6E8FEB86659FD93ull);
     for (std::size_t a = 1; a < set.alts.size(); ++a) {
         h ^= 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
         for (int p : set.alts[a].pivotPos) { h ^= static_cast<uint64_t>(p + 1); h *= 1099511628211ull; }

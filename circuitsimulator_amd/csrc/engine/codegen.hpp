@@ -90,6 +90,8 @@ struct GeneratorOptions {
                                  // cycles; +0.4 % on the bench, same box: gpurun_out/r03v)
     int group4 = 1;              // 1 = the library also carries the four-lanes-per-instance form of the group kernel (csim_tran_group4_kernel),
                                  // for circuits of up to 32 unknowns: the batches between the sixteen-lane and the lane-per-instance kernel
+    int placeSearch = 1;         // group kernels: rows are placed by a local search on the solves' planned instruction count instead of
+                                 // position-cyclically; bit 0: the four-lane kernel, bit 1: the sixteen-lane kernel
     int linChainBarrier = 0;     // linear sixteen-lane kernel: scheduling barrier after each critical link of the forward chain
     int linFactorBlock = 64;     // linear sixteen-lane library: lanes per workgroup of the factor kernel (0 = 16 / 32 / 64 by batch size;
                                  // measured on the N = 257 ladder at B = 8192, same box: 64 -> 3.09 ms per launch, by batch size (16) -> 3.16 ms)
@@ -100,7 +102,7 @@ struct GeneratorOptions {
 };
 
 // bumped whenever the emitted code or the launcher ABI of a generated library changes
-constexpr int kGeneratorRevision = 38;
+constexpr int kGeneratorRevision = 39;
 
 // identifies (topology, constants, schedule); names the generated library
 uint64_t scheduleHash(const csim_ir& ir, const PivotSchedule& sch);

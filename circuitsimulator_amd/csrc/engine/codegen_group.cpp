@@ -183,7 +183,10 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     // The first (most frequent) schedule places the rows; the others are planned over that placement, so
     // that all solve bodies share the launch-constant matrix part, the staging rows and the scatter tables.
     std::vector<GroupPlan> plans(1);
-    if (!buildGroupPlan(ir, ap, schedules[0], plans[0], nullptr, lanes)) return std::string();
+    GroupPlan placed;
+    const bool search = (gopt.placeSearch & (lanes == kGroupLanes ? 2 : 1)) != 0;
+    if (search && !optimizeGroupPlacement(ir, ap, schedules, lanes, placed)) return std::string();
+    if (!buildGroupPlan(ir, ap, schedules[0], plans[0], search ? &placed : nullptr, lanes)) return std::string();
     for (std::size_t a = 1; a < schedules.size(); ++a) {
         GroupPlan alt;
         if (!buildGroupPlan(ir, ap, schedules[a], alt, &plans[0], lanes)) return std::string();

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 
 namespace csim {
@@ -392,6 +393,70 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
         gp.iCellCon.insert(gp.iCellCon.end(), c.begin(), c.end());
         gp.iCellPtr.push_back(static_cast<int32_t>(gp.iCellCon.size()));
     }
+    return true;
+}
+
+// ---------------------------------------------------------------- placement search
+// wave-level instructions of one solve as the emitter will write it (broadcasts of a quad cost two moves)
+static double placementCost(const GroupPlan& gp)
+{
+    double c = (gp.G == 4 ? 2.0 : 1.0) * gp.nBcast + gp.nFma + gp.nMul + gp.nCmp + 2.0 * static_cast<double>(gp.stageRows.size());
+    int live = 0;
+    for (const auto& row : gp.classLive) for (uint8_t v : row) live += v ? 1 : 0;
+    c += 0.5 * live;                                         // every class is assembled once per solve (and costs registers)
+    for (const GroupPlan::Column& col : gp.cols)
+        for (const GroupPlan::Column::SlotMask& m : col.lMask)
+            if (!m.keepAll && m.suffix < 0) c += 1.0;        // an explicit lane mask instead of a launch-constant prefix factor
+    return c;
+}
+
+bool optimizeGroupPlacement(const csim_ir& ir, const AssemblyPlan& ap, const std::vector<PivotSchedule>& schedules, int lanes,
+                            GroupPlan& placement, double* costBefore, double* costAfter)
+{
+    if (schedules.empty()) return false;
+    GroupPlan first;
+    if (!buildGroupPlan(ir, ap, schedules[0], first, nullptr, lanes)) return false;
+    const int N = first.N;
+    placement = GroupPlan();
+    placement.N = N;
+    placement.G = lanes;
+    placement.finalPos = first.finalPos;
+    placement.rowAtPos = first.rowAtPos;
+    // (the staging rows live in LDS, and the four-lane kernel's image is sized to the last double: never more of them
+    // than the position-cyclic placement needs)
+    const std::size_t maxStage = first.stageRows.size();
+    auto total = [&](const GroupPlan& pl, double* out) {
+        double c = 0.0;
+        for (std::size_t a = 0; a < schedules.size(); ++a) {
+            GroupPlan gp;
+            if (!buildGroupPlan(ir, ap, schedules[a], gp, &pl, lanes)) return false;
+            if (gp.stageRows.size() > maxStage) return false;
+            c += (a == 0 ? 1.0 : 0.25) * placementCost(gp);  // the first schedule is the one most solves take
+        }
+        *out = c;
+        return true;
+    };
+    double best = 0.0;
+    if (!total(placement, &best)) return false;
+    if (costBefore) *costBefore = best;
+    // first-improvement local search over exchanges of two rows' cells; deterministic
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        bool improved = false;
+        for (int c1 = 0; c1 < N; ++c1)
+            for (int c2 = c1 + 1; c2 < N; ++c2) {
+                const int r1 = placement.rowAtPos[static_cast<std::size_t>(c1)], r2 = placement.rowAtPos[static_cast<std::size_t>(c2)];
+                std::swap(placement.rowAtPos[static_cast<std::size_t>(c1)], placement.rowAtPos[static_cast<std::size_t>(c2)]);
+                placement.finalPos[static_cast<std::size_t>(r1)] = c2;
+                placement.finalPos[static_cast<std::size_t>(r2)] = c1;
+                double c = 0.0;
+                if (total(placement, &c) && c < best - 1e-9) { best = c; improved = true; continue; }
+                std::swap(placement.rowAtPos[static_cast<std::size_t>(c1)], placement.rowAtPos[static_cast<std::size_t>(c2)]);
+                placement.finalPos[static_cast<std::size_t>(r1)] = c1;
+                placement.finalPos[static_cast<std::size_t>(r2)] = c2;
+            }
+        if (!improved) break;
+    }
+    if (costAfter) *costAfter = best;
     return true;
 }
 

@@ -107,6 +107,11 @@ struct GroupPlan {
 bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedule& sch, GroupPlan& out,
                     const GroupPlan* placement = nullptr, int lanes = kGroupLanes);
 
+// Row placement by local search (exchanges of two rows' cells) on the planned instruction count of the solves, the
+// first schedule's weighing most.  placement receives N, G, finalPos, rowAtPos: pass it to buildGroupPlan.
+bool optimizeGroupPlacement(const csim_ir& ir, const AssemblyPlan& ap, const std::vector<PivotSchedule>& schedules, int lanes,
+                            GroupPlan& placement, double* costBefore = nullptr, double* costAfter = nullptr);
+
 // Host interpreter of the plan, lane by lane, for ONE system: T[nTerms] are the term values of
 // plan.hpp.  Writes x[N]; *violated = a pivot check failed; *planError = a lane the kernel's all-lane
 // candidate test would see is neither a candidate, masked, nor an exact zero.  Used by the self test

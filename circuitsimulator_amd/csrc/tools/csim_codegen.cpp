@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <fstream>
 #include <iostream>
@@ -37,7 +38,8 @@ static std::string readSchedule(const std::string& path)
 
 // --selftest-group: run the sixteen-lanes-per-instance plan through its host interpreter on random term
 // values and compare with a plain dense elimination that uses the same pivot order (no GPU needed)
-static int selftestGroup(const csim_ir* ir, const csim::AssemblyPlan& ap, const csim::ScheduleSet& sch, int lanes)
+static int selftestGroup(const csim_ir* ir, const csim::AssemblyPlan& ap, const csim::ScheduleSet& sch, int lanes,
+                         const csim::GeneratorOptions& gopt)
 {
     int worstAlt = -1;
     double worst = 0.0;
@@ -45,7 +47,15 @@ static int selftestGroup(const csim_ir* ir, const csim::AssemblyPlan& ap, const 
     for (std::size_t alt = 0; alt < sch.alts.size(); ++alt) {
         csim::GroupPlan gp;
         // as the emitter does: alternatives are planned over the first schedule's row placement
-        if (!csim::buildGroupPlan(*ir, ap, sch.alts[alt], gp, alt ? &first : nullptr, lanes)) { std::printf("group plan: circuit does not fit\n"); return 3; }
+        // (and the first over the placement found by the search, where the generator options ask for it)
+        csim::GroupPlan placed;
+        const bool search = alt == 0 && (gopt.placeSearch & (lanes == csim::kGroupLanes ? 2 : 1)) != 0;
+        if (search) {
+            double c0 = 0.0, c1 = 0.0;
+            if (!csim::optimizeGroupPlacement(*ir, ap, sch.alts, lanes, placed, &c0, &c1)) { std::printf("group plan: circuit does not fit\n"); return 3; }
+            std::printf("placement search: planned instructions per solve (weighted over the schedules) %.1f -> %.1f\n", c0, c1);
+        }
+        if (!csim::buildGroupPlan(*ir, ap, sch.alts[alt], gp, alt ? &first : (search ? &placed : nullptr), lanes)) { std::printf("group plan: circuit does not fit\n"); return 3; }
         if (alt == 0) first = gp;
         const int N = ir->n_unknowns, LD = ap.LD;
         unsigned long long seed = 0x9E3779B97F4A7C15ull + alt;
@@ -148,7 +158,7 @@ int main(int argc, char** argv)
     // the library is NAMED by the topology hash (what an engine can compute before it
     // knows any schedule); the full hash is embedded for diagnostics
     const unsigned long long topo = csim::scheduleHash(*ir, csim::PivotSchedule::identity(ir->n_unknowns));
-    if (selftest) return selftestGroup(ir, ap, sch, selftest4 ? 4 : 16);
+    if (selftest) return selftestGroup(ir, ap, sch, selftest4 ? 4 : 16, gopt);
     if (hashOnly) { std::printf("%016llx\n", topo); return 0; }
 
     std::string label = netlist;

@@ -59,7 +59,17 @@ def test_group_plan_self_test_on_the_shipped_schedules(codegen):
                                capture_output=True, text=True)
             assert p.returncode == 0, (flag, name, p.stdout[-400:], p.stderr[-400:])
             assert "group plan self test: worst relative difference" in p.stdout
+            if flag.endswith("4"):
+                # the four-lane kernel's rows are placed by a local search on the planned instruction count (generator
+                # option place_search, bit 0); the interpreter above ran on THAT placement
+                before, after = (float(v) for v in p.stdout.split("(weighted over the schedules) ")[1].split("\n")[0].split(" -> "))
+                assert after < before, (name, before, after)
+            else:
+                assert "placement search" not in p.stdout
         assert p.stdout.count("group plan alt") >= 1
+    p = subprocess.run([codegen, "--opt", "place_search=0", "--selftest-group4", netlist_path("dbmixer.sp"),
+                        os.path.join(SCHED, "dbmixer.sched")], capture_output=True, text=True)
+    assert p.returncode == 0 and "placement search" not in p.stdout and "fma=292" in p.stdout      # position-cyclic
 
 
 def test_generated_library_carries_the_four_lane_kernel(codegen, tmp_path):
