@@ -170,7 +170,8 @@ int  csim_engine_set_kernel(csim_engine* eng, int32_t which);
  *   hipcc (CSIM_HIPCC, /opt/rocm/bin/hipcc), jit_timeout (CSIM_JIT_TIMEOUT, 600 s)
  *   jit_dc_alts (CSIM_JIT_DC_ALTS, 4), jit_dc_force (CSIM_JIT_DC_FORCE, off)  DC schedules kept by the JIT
  *   jit_gen_opts                            generator options of this engine's JIT, "key=value,key=value"
- *                                           (near_band, near_band_dc, stage_ahead, ...: engine/codegen.hpp);
+ *                                           (near_band, near_band_dc, stage_ahead, group4, place_search, ...:
+ *                                           engine/codegen.hpp);
  *                                           they are part of the hash a cached library is checked against
  *   near_test_rollback (0)                  test aid: every verified near-threshold decision is treated as a
  *                                           mismatch, so the roll-back path runs (results must not change)
