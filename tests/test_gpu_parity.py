@@ -528,6 +528,42 @@ def test_batch4096_invariances(engines, torch_mod):
         assert rel_err(whole["x"][:, b], o["x_final"]).max() < TOL
 
 
+def test_mid_batch_invariances(engines, torch_mod):
+    """12 288 dbmixer instances: the batch size at which the engine takes the four-lanes-per-instance kernel by itself
+    (16 instances per wavefront).  Same properties as at 4096: an instance's result does not depend on its neighbours,
+    on the chunking of the time axis or on the shard (6 144 each: the same kernel), and equals the oracle's."""
+    torch = torch_mod
+    nl, eng = engines["dbmixer"]
+    B, steps = 12288, 40
+    assert eng.lanes_for_batch(B) == 4 and eng.lanes_for_batch(B // 2) == 4
+    params = eng.mc_params(2024, 0.05, 0, B)
+    params[:, 13] = params[:, 12001]
+    whole = _run_tran(torch, eng, params, steps, nl.tstep)
+    assert not (whole["status"] & 0x27).any()
+    assert np.array_equal(whole["x"][:, 13], whole["x"][:, 12001]) and whole["iters"][13] == whole["iters"][12001]
+    chunked = _run_tran(torch, eng, params, steps, nl.tstep, chunks=[1, 19, 20])
+    assert np.array_equal(chunked["x"], whole["x"]) and np.array_equal(chunked["iters"], whole["iters"])
+    lo = _run_tran(torch, eng, params[:, :B // 2].contiguous(), steps, nl.tstep)
+    hi = _run_tran(torch, eng, params[:, B // 2:].contiguous(), steps, nl.tstep)
+    assert np.array_equal(np.concatenate([lo["x"], hi["x"]], axis=1), whole["x"])
+    assert np.array_equal(np.concatenate([lo["iters"], hi["iters"]]), whole["iters"])
+    # the same instances on the other fast kernels: equal NR totals, states within the bar
+    for lanes in (16, 1):
+        eng.set_option("lanes_per_instance", lanes)
+        try:
+            other = _run_tran(torch, eng, params, steps, nl.tstep)
+        finally:
+            eng.set_option("lanes_per_instance", 0)
+        assert np.array_equal(other["iters"], whole["iters"]), lanes
+        assert rel_err(other["x"].T, whole["x"].T).max() < TOL, lanes
+    cols = (0, 6143, 6144, B - 1)
+    ph = params[:, list(cols)].cpu().numpy()
+    for j, b in enumerate(cols):
+        o = _orc().tran(nl.ir_ptr, nl.n_unknowns, ph, j, nl.tstep, nl.tstep * steps, want_rows=False)
+        assert whole["iters"][b] == o["iters"], b
+        assert rel_err(whole["x"][:, b], o["x_final"]).max() < TOL, b
+
+
 # ------------------------------------------------ host-pointer API, edge cases
 
 def test_host_api_tstart_and_stride(engines):
