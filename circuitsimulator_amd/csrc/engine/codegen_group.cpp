@@ -1,4 +1,4 @@
-// codegen_group.cpp -- HIP emitter of the sixteen-lanes-per-instance scheduled transient kernel
+// codegen_group.cpp -- HIP emitter of the sixteen- and four-lanes-per-instance scheduled transient kernels
 // (plan and rationale: group_plan.hpp).  The emitted kernel has the parameters and the hand-over
 // protocol of the lane-per-instance kernel (codegen.cpp): fallback[], done[], violFlag.
 #include "group_plan.hpp"

@@ -1,4 +1,4 @@
-// group_plan.hpp -- plan of the SIXTEEN-LANES-PER-INSTANCE scheduled kernel.
+// group_plan.hpp -- plan of the SIXTEEN- (and FOUR-) LANES-PER-INSTANCE scheduled kernels.
 //
 // The lane-per-instance kernel (codegen.cpp) needs 64 instances per wavefront; BASELINE's
 // headline batch (4096 instances) then fills 64 of the chip's 1024 SIMDs.  This plan splits
@@ -22,6 +22,11 @@
 //   * back substitution runs column-wise: x_j is formed in lane j%16, broadcast, and
 //     subtracted from the right-hand sides of the rows above; rows at or below j hold dead
 //     right-hand sides by then, so they need no protection.
+// Four lanes per instance (lanes = 4: a DPP quad, 16 instances per wavefront, up to 8 rows per lane) is the same plan
+// with G = 4; there the rows are not placed position-cyclically but by optimizeGroupPlacement() below (which rows share
+// a slot decides how many update instructions a column costs), so pivot rows sit at arbitrary lanes and the finished
+// rows of a slot are removed by explicit lane masks -- the form every ALTERNATIVE schedule has always had, since
+// alternatives are planned over the first schedule's placement.
 // Arithmetic differences from the reference (inside the 1e-9 bar, like the lane-per-instance
 // kernel): FMA contraction, one Newton-refined reciprocal per pivot, the per-iteration matrix
 // is formed as (terms that do not change within a time step) + (MOSFET terms) instead of one
@@ -46,8 +51,8 @@ constexpr int kGroupLanes = 16;
 
 struct GroupPlan {
     int N = 0, S = 0;                        // unknowns, slots per lane = ceil(N / G)
-    int G = kGroupLanes;
-    int ldsDoubles = 0;                    // LDS image of one instance in the emitted kernel (set by emitGroupKernel)                     // lanes per instance: 16 (one DPP row) or 4 (one quad; 16 instances per wavefront)
+    int G = kGroupLanes;                     // lanes per instance: 16 (one DPP row) or 4 (one quad; 16 instances per wavefront)
+    int ldsDoubles = 0;                      // LDS image of one instance in the emitted kernel (set by emitGroupKernel)
     std::vector<int> finalPos;               // original row -> pivot position
     std::vector<int> rowAtPos;               // pivot position -> original row
 
