@@ -406,7 +406,8 @@ static double placementCost(const GroupPlan& gp)
     c += 0.5 * live;                                         // every class is assembled once per solve (and costs registers)
     for (const GroupPlan::Column& col : gp.cols)
         for (const GroupPlan::Column::SlotMask& m : col.lMask)
-            if (!m.keepAll && m.suffix < 0) c += 1.0;        // an explicit lane mask instead of a launch-constant prefix factor
+            if (!m.keepAll && m.suffix < 0) c += gp.G == 4 ? 1.0 : 4.0;   // an explicit lane mask instead of a launch-constant prefix factor
+                                                                          // (a quad has 14 such masks, they stay in registers; a row of 16 does not)
     return c;
 }
 
