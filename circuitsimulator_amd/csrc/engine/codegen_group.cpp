@@ -315,8 +315,8 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
         // TS (compact slots; zeroSlot = always 0), and TT -- needed while the launch-constant matrix part and the
         // history coefficients are gathered, dead afterwards -- shares its place with TS and the staging rows.
         // XP has no ground cell of its own (XH, above), and the staging rows' dummy is the one cell lanes without a
-        // MOSFET scatter into.  The stride is then padded to 4 (mod 8) doubles: a ds_read_b64 serves 32 lanes -- eight
-        // instances reading 8 consecutive dwords each -- per pass over the 64 banks, and with that stride the eight start
+        // MOSFET scatter into.  The stride is then padded to 4 (mod 8) doubles: a 64-bit LDS access serves 16 lanes -- four
+        // instances reading 8 consecutive dwords each -- per pass over the 64 banks, and with that stride they start
         // on different multiples of 8 dwords (measured: a stride of 320 doubles, all instances on the same banks, cost
         // 12 % of the kernel).
         oPL = oXP + NP;
