@@ -543,7 +543,7 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
             << "        if (!__any(inb && !viol)) break;\n"
             << "        const double scale = (double)step / " << K.dc_ramp_steps << ";\n"
             << "        // baseGmin(scale) (dcanalysis.hpp:45-48), every product and sum rounded separately\n"
-            << "        const double gb = __dadd_rn(__dmul_rn(" << lit(K.gmin_high) << ", 1.0 - scale), __dmul_rn(" << lit(K.gmin_low) << ", scale));\n"
+            << "        const double gb = csim_add_rn(csim_mul_rn(" << lit(K.gmin_high) << ", 1.0 - scale), csim_mul_rn(" << lit(K.gmin_low) << ", scale));\n"
             << "        double gminv = gb;\n"
             << "        double prevErr = INFINITY;\n"
             << "        const long long vo = splitFlag ? (long long)step : 0LL;\n";
@@ -905,15 +905,15 @@ int emitKernel(std::ostringstream& src, const csim_ir& ir, const AssemblyPlan& a
               << g.ind << "            const bool first = (iter == 0 || !isfinite(prevErr));\n"
               << g.ind << "            const double band = " << lit(gopt.nearBandDc) << " * err;\n"
               << g.ind << "            if (fabs(err - " << lit(K.dc_tol) << ") <= " << lit(gopt.nearBandDc * K.dc_tol) << " ||\n"
-              << g.ind << "                (!first && (fabs(err - __dmul_rn(prevErr, " << lit(K.slow_ratio) << ")) <= band ||\n"
-              << g.ind << "                            fabs(err - __dmul_rn(prevErr, " << lit(K.fast_ratio) << ")) <= band))) { viol = true; active = false; }\n"
+              << g.ind << "                (!first && (fabs(err - csim_mul_rn(prevErr, " << lit(K.slow_ratio) << ")) <= band ||\n"
+              << g.ind << "                            fabs(err - csim_mul_rn(prevErr, " << lit(K.fast_ratio) << ")) <= band))) { viol = true; active = false; }\n"
               << g.ind << "        }\n";
         for (int i = 0; i < N; ++i) o << g.ind << "        X(" << i << ") = xn" << i << ";\n";
         o << g.ind << "        double gnext;\n"
           << g.ind << "        if (iter == 0 || !isfinite(prevErr)) gnext = gb;                                   // :280-282\n"
-          << g.ind << "        else if (err > __dmul_rn(prevErr, " << lit(K.slow_ratio) << ")) gnext = fmin(__dmul_rn(gminv, 2.0), " << lit(K.gmin_abs_max) << ");   // :285-288\n"
-          << g.ind << "        else if (err < __dmul_rn(prevErr, " << lit(K.fast_ratio) << ")) gnext = __dadd_rn(__dmul_rn(0.5, gminv), __dmul_rn(0.5, gb));   // :289-293\n"
-          << g.ind << "        else gnext = __dadd_rn(__dmul_rn(0.7, gminv), __dmul_rn(0.3, gb));               // :296\n"
+          << g.ind << "        else if (err > csim_mul_rn(prevErr, " << lit(K.slow_ratio) << ")) gnext = fmin(csim_mul_rn(gminv, 2.0), " << lit(K.gmin_abs_max) << ");   // :285-288\n"
+          << g.ind << "        else if (err < csim_mul_rn(prevErr, " << lit(K.fast_ratio) << ")) gnext = csim_add_rn(csim_mul_rn(0.5, gminv), csim_mul_rn(0.5, gb));   // :289-293\n"
+          << g.ind << "        else gnext = csim_add_rn(csim_mul_rn(0.7, gminv), csim_mul_rn(0.3, gb));               // :296\n"
           << g.ind << "        gminv = gnext;\n"
           << g.ind << "        prevErr = err;\n"
           << g.ind << "        if (err < " << lit(K.dc_tol) << ") active = false;                                 // :150\n"
@@ -1048,6 +1048,14 @@ std::string generateTranKernelSource(const csim_ir& ir, const AssemblyPlan& ap, 
         << "#include <hip/hip_runtime.h>\n#include <stdint.h>\n\n"
         << "#define ST_TRAN_NONFINITE 0x0001u\n#define ST_TRAN_NONCONV 0x0002u\n#define ST_DC_NONCONV 0x0008u\n#define ST_SCHED_FAITHFUL 0x0100u\n\n"
         << "#define Q(k) lds[(k) * 64 + lane]\n#define X(i) Q(i)\n#define S(j) Q(" << N << " + (j))\n\n"
+        << "// a product / a sum that is rounded by itself wherever it is used (the DC controller's gmin arithmetic,\n"
+        << "// src/dcanalysis.cpp:45-48,285-296).  NOT hip's __dmul_rn / __dadd_rn: those are inline functions of a header\n"
+        << "// compiled with contraction allowed, and inlined here their operations fuse -- base gmin of ramp step 2 came out\n"
+        << "// one ulp off, visible on a node whose diagonal is gmin alone (tools/fuzz_generated.py seed 10266)\n"
+        << "#pragma clang fp contract(off)\n"
+        << "__device__ __forceinline__ double csim_mul_rn(double a, double b) { return a * b; }\n"
+        << "__device__ __forceinline__ double csim_add_rn(double a, double b) { return a + b; }\n"
+        << "#pragma clang fp contract(fast)\n"
         << "// refined reciprocal for the pivots: v_rcp_f64 + one cubic step (three dependent FMAs)\n"
         << "__device__ __forceinline__ double clamp01_cg(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }\n"
         << "__device__ __forceinline__ double rcp_nr(double a)\n{\n"

@@ -91,6 +91,39 @@ def test_faithful_dc_kernel_is_bitwise_the_general_kernel(torch_mod, dbmixer_nl)
     assert rel_err(xs.cpu().numpy().T, xg.cpu().numpy().T).max() < TOL
 
 
+def test_faithful_dc_kernel_on_a_node_whose_diagonal_is_gmin_alone(torch_mod, tmp_path, monkeypatch):
+    """tools/fuzz_generated.py seed 10266 (N = 13): node n8 is nothing but a MOSFET gate, its matrix row is gmin on the
+    diagonal -- so the LAST BIT of gmin shows in the operating point (every other circuit adds gmin to conductances six
+    orders larger).  Until round 3 the generated DC kernels formed the controller's gmin (src/dcanalysis.cpp:45-48,
+    285-296) with hip's __dmul_rn / __dadd_rn, whose header-inlined operations the compiler fused: base gmin of ramp step 2
+    came out one ulp off, and 34 of the 35 instances that finished on the faithful DC kernel differed from the general
+    kernel (by up to 7.5e-13 V on n8).  Now: bit for bit the general kernel's operating points, and the oracle's."""
+    from circuitsimulator_amd import Engine, Netlist
+    _need_hipcc()
+    monkeypatch.setenv("CSIM_JIT_DIR", str(tmp_path / "jit"))
+    seed = 10266
+    rs = np.random.RandomState(seed)
+    nl = Netlist.from_text(_random_netlist(rs, rs.randint(3, 25), rs.randint(0, 8)))
+    assert nl.n_unknowns == 13 and "n8" in nl.eq_names
+    eng = Engine(nl, 0)
+    B = 70
+    params = eng.mc_params(seed, 0.05, 0, B)
+    eng.set_kernel("general")
+    xg, itg, stg = eng.dc(params)
+    eng.set_kernel("auto")
+    eng.jit_scheduled(params, plan_steps=50)
+    assert len(eng.loaded_schedules()[1]) >= 2              # the ramp needs two pivot sequences (the gate node's MOSFET turns on)
+    xf, itf, stf = eng.dc(params)
+    kept = (stf & 0x80) == 0                                # finished on the generated kernel (the others: replayed by the general one)
+    assert int(kept.sum()) >= B // 3
+    assert torch_mod.equal(itf, itg)
+    assert torch_mod.equal(xf, xg)                          # ... bit for bit, replayed or not
+    ph = params.cpu().numpy()
+    for b in [int(v) for v in kept.nonzero().flatten()[:3]]:
+        xo, ito, sto = _orc().dc(nl.ir_ptr, nl.n_unknowns, ph, b)
+        assert ito == int(itf[b]) and np.array_equal(xf[:, b].cpu().numpy(), xo), b
+
+
 @pytest.mark.parametrize("lanes", [16, 4, 1])
 def test_near_threshold_decisions_are_verified_and_rolled_back(torch_mod, dbmixer_nl, tmp_path, monkeypatch, lanes):
     """dbmixer.sp kernels generated with a guard band of 15 % (the shipped band is 2e-8: its events are too rare to

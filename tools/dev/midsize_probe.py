@@ -8,7 +8,7 @@ os.environ.setdefault("CSIM_JIT_DIR", "/tmp/csim_jit_mid")
 spec = importlib.util.spec_from_file_location("tgp", os.path.join(ROOT, "tests", "test_gpu_parity.py"))
 t = importlib.util.module_from_spec(spec); spec.loader.exec_module(t)
 from circuitsimulator_amd import Engine, Netlist
-for stages in (int(a) for a in (sys.argv[1:] or ["30", "60"])):
+for stages in (int(a) for a in (sys.argv[1:] or ["30", "37", "45"])):
     nl = Netlist.from_text(t._amplifier_line(stages))
     eng = Engine(nl, 0)
     steps = 100
