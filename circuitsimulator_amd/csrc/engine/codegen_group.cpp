@@ -201,6 +201,9 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     const bool multi = plans.size() > 1;
     const int N = gp.N, S = gp.S, G = gp.G;
     const bool quad = G != kGroupLanes;                        // four lanes per instance (DPP quads), 16 instances per wavefront
+    // the small LDS image (see the carve-up below): always for four lanes per instance, and for sixteen from five rows
+    // per lane on -- at N = 65 the full image is 90 KB per workgroup, one workgroup per CU
+    const bool diet = quad || S > 4;
     const int perWave = 64 / G;
     const std::string GS = std::to_string(G), BC = quad ? "grp_bc4<" : "grp_bc<";
     const csim_consts& K = ir.k;
@@ -246,7 +249,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     std::vector<int> stepSlot(static_cast<std::size_t>(nT1), -1);
     std::vector<int32_t> srcOff(srcTab.size(), 0), srcSlot(srcTab.size(), 0);
     int nSrcParams = 0, zeroSlot = 0;
-    if (quad)
+    if (diet)
         for (std::size_t i = 0; i < srcTab.size(); ++i) {
             const int e = srcTab[i];
             if (e < 0) continue;
@@ -259,9 +262,9 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     {
         const int dummy = ap.nTerms;
         // (quad: the history reads go through XH = XP - 1, whose entry 0 is the iterate's ground cell XS[NP])
-        auto node = [&](int eq) { return quad ? (eq >= 0 ? eq + 1 : 0) : (eq >= 0 ? eq : NP); };
+        auto node = [&](int eq) { return diet ? (eq >= 0 ? eq + 1 : 0) : (eq >= 0 ? eq : NP); };
         auto add = [&](int gterm, int a, int b, int out) {
-            if (quad) { stepSlot[static_cast<std::size_t>(out)] = zeroSlot; out = zeroSlot++; }
+            if (diet) { stepSlot[static_cast<std::size_t>(out)] = zeroSlot; out = zeroSlot++; }
             hA.push_back(node(a) | (node(b) << 8));
             hG.push_back(gterm | (out << 16));
         };
@@ -277,7 +280,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
                 add(tb + T_M_GCF, q[0], q[3], tb + T_M_IHDB);
             }
         }
-        while (hA.size() % G) { hA.push_back(node(-1) | (node(-1) << 8)); hG.push_back(dummy | ((quad ? zeroSlot : dummy) << 16)); }
+        while (hA.size() % G) { hA.push_back(node(-1) | (node(-1) << 8)); hG.push_back(dummy | ((diet ? zeroSlot : dummy) << 16)); }
         if (ap.nTerms >= 65535 || NP >= 255) return std::string();
     }
     const int histRounds = static_cast<int>(hA.size()) / G;
@@ -291,7 +294,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
             for (int lane = 0; lane < G; ++lane) {
                 const int lo = gp.iCellPtr[static_cast<std::size_t>(s * G + lane)], hi = gp.iCellPtr[static_cast<std::size_t>(s * G + lane + 1)];
                 int con = lo + t < hi ? gp.iCellCon[static_cast<std::size_t>(lo + t)] : 2 * ap.nTerms;   // padding: + the dummy zero
-                if (quad) {
+                if (diet) {
                     const int sl = (con >> 1) == ap.nTerms ? zeroSlot : stepSlot[static_cast<std::size_t>(con >> 1)];
                     if (sl < 0) return std::string();          // a right-hand-side term that is not a per-step term: cannot happen
                     con = 2 * sl + (con & 1);
@@ -300,7 +303,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
             }
     }
     o << intArray("grp_src", srcTab) << intArray("grp_hA", hA) << intArray("grp_hG", hG) << intArray("grp_rhs", rhsIdx);
-    if (quad) o << intArray("grp_srcOff", srcOff) << intArray("grp_srcSlot", srcSlot);
+    if (diet) o << intArray("grp_srcOff", srcOff) << intArray("grp_srcSlot", srcSlot);
 
     // LDS carve-up per instance (doubles)
     int oXS = 0, oXP = oXS + NP + 1, oTT = oXP + NP + 1, oTS = oTT + nT1, oPL = oTS + 2 * nT1, oST = oPL + ir.n_params;
@@ -309,7 +312,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     // doubles (mod 32) puts the second group of a pass on the other half of the banks.  Measured: no fewer conflicts
     // (codegen.hpp), so off by default.
     int instDoubles = oST + (nStage + 1) * G;
-    if (quad) {
+    if (diet) {
         // Four lanes per instance put 16 instances into a workgroup, and four workgroups must share a CU's 160 KB (one
         // wave per SIMD): 320 doubles per instance.  So: only the sources' parameters (PL), only the per-step terms in
         // TS (compact slots; zeroSlot = always 0), and TT -- needed while the launch-constant matrix part and the
@@ -324,7 +327,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
         oTT = oTS;
         oST = oTS + 2 * (zeroSlot + 1);
         instDoubles = std::max(oST + nStage * G + (gopt.dummyOneCell ? 1 : G), oTT + nT1);
-        while (instDoubles % 8 != 4) ++instDoubles;
+        while (quad && instDoubles % 8 != 4) ++instDoubles;
     }
     while (gopt.ldsPad && instDoubles % 32 != 16) ++instDoubles;
     if (instDoubles * 8 * perWave > 150 * 1024) return std::string();
@@ -359,19 +362,19 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
       << "    double* const TS = lds + q * " << instDoubles << " + " << oTS << ";   // per-step terms with sign: TS[2t] = +TT[t], TS[2t+1] = -TT[t]\n"
       << "    double* const PL = lds + q * " << instDoubles << " + " << oPL << ";   // this instance's parameters\n"
       << "    double* const ST = lds + q * " << instDoubles << " + " << oST << ";   // MOSFET staging rows [row][16]; last row = dummy\n"
-      << (quad ? "    double* const XH = XP - 1;          // history view of XP: XH[0] = XS[" + std::to_string(NP) + "] = 0 (ground), XH[1 + i] = XP[i]\n" : "")
+      << (diet ? "    double* const XH = XP - 1;          // history view of XP: XH[0] = XS[" + std::to_string(NP) + "] = 0 (ground), XH[1 + i] = XP[i]\n" : "")
       << "    const unsigned long long rowBits = " << (quad ? "0xFull" : "0xFFFFull") << " << (" << G << " * q);\n"
       << "    auto P = [&](int slot) -> double { return params[(long long)slot * SB + bb]; };\n\n";
 
     // ---- launch setup: zero staging, constants, terms
-    if (!quad)
+    if (!diet)
         o << "    for (int i = g; i < " << (nStage + 1) * G << "; i += " << GS << ") ST[i] = 0.0;\n";
     o << "    for (int i = g; i < " << nT1 << "; i += " << GS << ") TT[i] = 0.0;\n";
-    if (!quad)
+    if (!diet)
         o << "    for (int i = g; i < " << 2 * nT1 << "; i += " << GS << ") TS[i] = 0.0;\n"
           << "    for (int i = g; i < " << ir.n_params << "; i += " << GS << ") PL[i] = P(i);\n";
     o
-      << "    if (g == 0) { XS[" << NP << "] = 0.0; " << (quad ? std::string() : "XP[" + std::to_string(NP) + "] = 0.0; ") << "}\n"
+      << "    if (g == 0) { XS[" << NP << "] = 0.0; " << (diet ? std::string() : "XP[" + std::to_string(NP) + "] = 0.0; ") << "}\n"
       << "    grp_sync();\n"
       << "    bool badL = false;\n"
       << "    for (int e = g; e < " << ir.n_elems << "; e += " << GS << ") {          // terms constant over the launch (tanalisis.cpp:59-80,294-341)\n"
@@ -419,9 +422,9 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
     for (int r = 0; r < srcRounds; ++r)
         o << "    const int se" << r << " = grp_src[" << r * G << " + g];       // source evaluated by this lane in round " << r << " (-1: none)\n"
           << "    const int sq" << r << " = se" << r << " >= 0 ? se" << r << " : 0;\n"
-          << "    const int ssl" << r << " = grp_slot[sq" << r << "], stb" << r << (quad ? " = grp_srcSlot[" + std::to_string(r * G) + " + g]" : " = grp_tbase[sq" + std::to_string(r) + "]") << ", swv" << r << " = grp_wave[sq" << r
+          << "    const int ssl" << r << " = grp_slot[sq" << r << "], stb" << r << (diet ? " = grp_srcSlot[" + std::to_string(r * G) + " + g]" : " = grp_tbase[sq" + std::to_string(r) + "]") << ", swv" << r << " = grp_wave[sq" << r
           << "], swn" << r << " = grp_waveN[sq" << r << "];\n";
-    if (quad)
+    if (diet)
         for (int r = 0; r < srcRounds; ++r)
             o << "    const int spo" << r << " = grp_srcOff[" << r * G << " + g];\n"
               << "    if (se" << r << " >= 0) {\n"
@@ -430,7 +433,7 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
               << "    }\n";
     for (int r = 0; r < histRounds; ++r)
         o << "    const int hA" << r << " = grp_hA[" << r * G << " + g], hG" << r << " = grp_hG[" << r * G << " + g];\n";
-    if (quad) {
+    if (diet) {
         for (int r = 0; r < histRounds; ++r) o << "    const double hc" << r << " = TT[hG" << r << " & 0xFFFF];\n";
         o << "    grp_sync();        // TT is dead from here on: its place is taken by the per-step terms and the staging rows\n"
           << "    for (int i = g; i < " << 2 * (zeroSlot + 1) << "; i += " << GS << ") TS[i] = 0.0;\n"
@@ -505,13 +508,13 @@ std::string emitGroupKernel(const csim_ir& ir, const AssemblyPlan& ap, const std
       << "        // same array): the history operands and the first iteration's MOSFET inputs fly while the sources are\n"
       << "        // evaluated, the right-hand-side terms in one batch after the writes.\n";
     for (int r = 0; r < histRounds; ++r)
-        o << "        const double " << (quad ? std::string() : "hc" + std::to_string(r) + " = TT[hG" + std::to_string(r) + " & 0xFFFF], ") << "hp" << r << " = " << (quad ? "XH" : "XP") << "[hA" << r << " & 0xFF], hq" << r << " = " << (quad ? "XH" : "XP") << "[hA" << r << " >> 8];\n";
+        o << "        const double " << (diet ? std::string() : "hc" + std::to_string(r) + " = TT[hG" + std::to_string(r) + " & 0xFFFF], ") << "hp" << r << " = " << (diet ? "XH" : "XP") << "[hA" << r << " & 0xFF], hq" << r << " = " << (diet ? "XH" : "XP") << "[hA" << r << " >> 8];\n";
     if (!piped)
         for (int r = 0; r < mosRounds; ++r)
             o << "        double vd" << r << " = XS[mD" << r << "], vg" << r << " = XS[mG" << r << "], vs" << r << " = XS[mS" << r << "];\n";
     for (int r = 0; r < srcRounds; ++r)
         o << "        if (se" << r << " >= 0) {\n"
-          << "            const double v = grp_source_tran([&](int i) { return PL[" << (quad ? "spo" : "ssl") << r << " + i]; }, swv" << r << ", swn" << r << ", tNow, " << lit(K.pi) << ");\n"
+          << "            const double v = grp_source_tran([&](int i) { return PL[" << (diet ? "spo" : "ssl") << r << " + i]; }, swv" << r << ", swn" << r << ", tNow, " << lit(K.pi) << ");\n"
           << "            TS[2 * stb" << r << "] = v; TS[2 * stb" << r << " + 1] = -v;\n"
           << "        }\n";
     for (int r = 0; r < histRounds; ++r)

@@ -40,7 +40,10 @@ bool buildGroupPlan(const csim_ir& ir, const AssemblyPlan& ap, const PivotSchedu
     if (G != 16 && G != 4) return false;
     const unsigned laneAll = (1u << G) - 1u;
     gp.G = G;
-    if (N <= 0 || N > (G == 16 ? 4 : 8) * G) return false;         // four slots: the live classes of N = 57 still compile (106 spilled registers)
+    // sixteen lanes: up to six rows per lane (N <= 96).  From five rows on the kernel spills (N = 65: 216 registers, N = 95
+    // more) and takes the small LDS image of the four-lane kernel; it still beats the lane-per-instance kernel threefold at
+    // B = 4096 (N = 65: 2.8e8 against 7.6e7, N = 95: 4.5e7 against ~1.4e7) and the general kernel by 13 ... 50.
+    if (N <= 0 || N > (G == 16 ? 6 : 8) * G) return false;
     if (static_cast<int>(sch.pivotPos.size()) != N) return false;
     gp.N = N;
     gp.S = (N + G - 1) / G;

@@ -104,7 +104,7 @@ struct GroupPlan {
     int depthElimination = 0, depthSolve = 0;
 };
 
-// false: the circuit does not fit this kernel (N > 48, ...).  placement: where the rows sit.  The first
+// false: the circuit does not fit this kernel (sixteen lanes: N > 96; four lanes: N > 32).  placement: where the rows sit.  The first
 // schedule of a circuit places them itself (row of final pivot position p at lane p%16, slot p/16); further
 // alternatives are planned over THAT placement (placement = the first plan), so that they share the
 // step-constant matrix part and the MOSFET staging: their pivot rows then sit at arbitrary lanes and the

@@ -322,6 +322,33 @@ def test_group_kernel_four_slots_55_unknowns(torch_mod, tmp_path, monkeypatch):
     assert fast["iters"][3] == o["iters"] and rel_err(fast["x"][:, 3], o["x_final"]).max() < TOL
 
 
+@pytest.mark.parametrize("stages", [30, 45])
+def test_group_kernel_five_and_six_slots(torch_mod, tmp_path, monkeypatch, stages):
+    """65 <= N <= 96: five and six rows per lane (amplifier lines of 30 / 45 stages: N = 65 / 95).  From five rows on the
+    sixteen-lane kernel takes the small LDS image of the four-lane kernel (sources' parameters only, compact per-step
+    terms, term table sharing its place with the staging rows) and spills registers; it is still the fastest kernel for
+    such circuits up to mid-size batches.  Per-step NR counts, status and states against the general kernel, one instance
+    against the oracle."""
+    from circuitsimulator_amd import Engine, Netlist
+    monkeypatch.setenv("CSIM_JIT_DIR", str(tmp_path / "jit"))
+    nl = Netlist.from_text(_amplifier_line(stages))
+    assert nl.n_unknowns == 2 * stages + 5 and 64 < nl.n_unknowns <= 96
+    eng = Engine(nl, 0)
+    B, steps = 24, 120
+    params = eng.mc_params(5, 0.03, 0, B)
+    slow = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True)
+    eng.jit_scheduled(params, plan_steps=steps)
+    assert eng.tran_kernel == "scheduled" and "group16" in eng.sched_info["text"] and "group4" not in eng.sched_info["text"]
+    assert eng.lanes_for_batch(B) == 16
+    fast = _run_tran(torch_mod, eng, params, steps, nl.tstep, want_step_iters=True, chunks=[50, 70])
+    assert np.array_equal(fast["step_iters"], slow["step_iters"])
+    assert np.array_equal(fast["status"] & NOFB, slow["status"])
+    assert rel_err(fast["x"].T, slow["x"].T).max() < TOL
+    assert ((fast["status"] & (FALLBACK | FAITHFUL)) == 0).sum() > B // 2        # the group kernel itself did the work
+    o = _orc().tran(nl.ir_ptr, nl.n_unknowns, params.cpu().numpy(), 3, nl.tstep, nl.tstep * steps, want_rows=False)
+    assert fast["iters"][3] == o["iters"] and rel_err(fast["x"][:, 3], o["x_final"]).max() < TOL
+
+
 def test_group_kernel_carries_every_recorded_schedule(engines, torch_mod):
     """buffer.sp at its shipped step alternates between ten pivot schedules.  The group kernel has one
     solve body per schedule, all over the first schedule's row placement (pivot rows at arbitrary lanes,
