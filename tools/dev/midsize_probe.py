@@ -11,6 +11,7 @@ from circuitsimulator_amd import Engine, Netlist
 for stages in (int(a) for a in (sys.argv[1:] or ["30", "37", "45"])):
     nl = Netlist.from_text(t._amplifier_line(stages))
     eng = Engine(nl, 0)
+    if os.environ.get("CSIM_PROBE_GENOPTS"): eng.set_option("jit_gen_opts", os.environ["CSIM_PROBE_GENOPTS"])
     steps = 100
     def run(label, B, params):
         x, dc_it, st = eng.dc(params)
