@@ -20,6 +20,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--first", type=int, default=20000)
     ap.add_argument("--count", type=int, default=100)
+    ap.add_argument("--stress", action="store_true",
+                    help="add degenerate parts to every circuit: a node that is only a MOSFET gate, a node that hangs on "
+                         "capacitors only (their matrix rows are gmin alone in DC: the last bit of gmin shows)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -31,7 +34,19 @@ def main():
     bad = n_run = n_kept_dc = n_kept_tr = 0
     for seed in range(a.first, a.first + a.count):
         rs = np.random.RandomState(seed)
-        nl = Netlist.from_text(t._random_netlist(rs, rs.randint(3, 25), rs.randint(0, 8)))
+        text = t._random_netlist(rs, rs.randint(3, 25), rs.randint(0, 8))
+        if a.stress:
+            nodes = sorted({w for ln in text.splitlines() if ln[:1] in "RCL" for w in ln.split()[1:3] if w.startswith("n")})
+            extra = []
+            if len(nodes) >= 2:
+                d_, s_ = rs.choice(nodes, 2, replace=False)
+                extra.append("MG1 %s gx1 %s n %.3ge-6 0.35e-6 2" % (d_, s_, rs.uniform(5, 40)))          # gx1: a gate and nothing else
+                extra.append("MG2 %s gx2 vdd p %.3ge-6 0.35e-6 1" % (rs.choice(nodes), rs.uniform(5, 40)))
+                extra.append("CG2 gx2 %s %.4g" % (rs.choice(nodes), 10 ** rs.uniform(-14, -12)))           # gx2: a gate and a capacitor
+                extra.append("CX1 cx1 0 %.4g" % 10 ** rs.uniform(-14, -12))                                 # cx1: capacitors only
+                extra.append("CX2 cx1 %s %.4g" % (rs.choice(nodes), 10 ** rs.uniform(-14, -12)))
+            text = text.replace(".MODEL 1", "\n".join(extra) + "\n.MODEL 1", 1)
+        nl = Netlist.from_text(text)
         eng = Engine(nl, 0)
         B, steps = 70, 50
         params = eng.mc_params(seed, 0.05, 0, B)
