@@ -159,7 +159,7 @@ int  csim_engine_set_kernel(csim_engine* eng, int32_t which);
  *   hybrid_steps  (CSIM_HYBRID_STEPS, 64)   most steps the general kernel keeps an instance per round
  *   lanes_per_instance (CSIM_LANES_PER_INSTANCE, 0)  scheduled transient kernel: 1 = lane per instance,
  *                                           4 = four lanes per instance (circuits of up to 32 unknowns),
- *                                           16 = sixteen lanes per instance, 0 = chosen by batch size
+ *                                           16 = sixteen lanes per instance (up to 96 unknowns), 0 = chosen by batch size
  *                                           (<= 4096: 16; up to 16 384: 4; beyond: 1)
  *   sched_variant (CSIM_SCHED_VARIANT, 0)   tuning kernels of a generated library (2 rich, 10+k sweep)
  *   auto_jit (CSIM_AUTO_JIT, off)           csim_tran_batch specialises a new circuit on first use
