@@ -235,3 +235,53 @@ def test_generated_faithful_transient_kernel_with_ten_alternatives_on_the_host(c
     assert fb == 0 and done == steps, (fb, done)
     assert iters == o["iters"] and np.array_equal(per_step, o["step_iters"])
     assert np.array_equal(x, o["x_final"]), np.abs(x - o["x_final"]).max()
+
+
+def test_generated_fast_transient_kernel_on_the_host_against_the_oracle(codegen, tmp_path):
+    """The FAST lane-per-instance kernel (csim_tran_sched_kernel: reciprocal pivots, contraction allowed, near-threshold
+    guard) compiled for the host with FMA contraction on: not bit-faithful by design -- per-step NR counts equal to the
+    oracle's and states within the 1e-9 bar, 400 steps of two dbmixer Monte-Carlo instances, nothing handed over."""
+    from circuitsimulator_amd import Netlist
+    from oracle import binding as orc
+    from conftest import rel_err
+    nl = Netlist.from_file(netlist_path("dbmixer.sp"))
+    workdir = str(tmp_path)
+    hip = os.path.join(workdir, "k.hip")
+    p = subprocess.run([codegen, netlist_path("dbmixer.sp"), os.path.join(SCHED, "dbmixer.sched"), hip], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    lines = open(hip).read().split("\n")
+    at = next(i for i, l in enumerate(lines) if l.startswith("csim_tran_sched_kernel(const double*"))
+    assert lines[at - 1].startswith('extern "C" __global__')
+    end = next(i for i in range(at + 1, len(lines)) if lines[i].startswith('extern "C" __global__') or lines[i].startswith("#pragma clang fp"))
+    body = "void\n" + "\n".join(lines[at:end])
+    main = HOST_MAIN_TRAN.replace("csim_tran_faithful_kernel", "csim_tran_sched_kernel").replace(
+        "viol, nullptr, nullptr, nullptr, nullptr);", "viol, nearX, &nearStep, &nearIt, &nearItAfter);").replace(
+        "static int stepIters[200000];", "static int stepIters[200000]; static double nearX[2048]; int nearStep = 0, nearIt = 0; long long nearItAfter = 0;")
+    rcp = ("static inline double __builtin_amdgcn_rcp(double a) { return 1.0 / a; }\nusing std::fma;\n"
+           "static inline double rcp_nr(double a) { const double r = __builtin_amdgcn_rcp(a); const double e = fma(-a, r, 1.0); return fma(fma(e, e, e), r, r); }\n")
+    cpp = os.path.join(workdir, "s_host.cpp")
+    with open(cpp, "w") as f:
+        f.write(HOST_PRELUDE + HOST_PRELUDE_TRAN + rcp + body + main)
+    exe = os.path.join(workdir, "s_host")
+    p = subprocess.run(["g++", "-O1", "-ffp-contract=fast", "-mfma", "-std=c++17", "-w", cpp, "-o", exe], capture_output=True, text=True)
+    if p.returncode != 0 and "mfma" in p.stderr:
+        pytest.skip("no FMA on this host")
+    assert p.returncode == 0, p.stderr[-2000:]
+    ph = nl.mc_params_host(12345, 0.05, 0, 8)
+    steps = 400
+    for b in (1, 6):
+        xdc, _, _ = orc.dc(nl.ir_ptr, nl.n_unknowns, ph, b)
+        text = "%d %d %d %s\n" % (ph.shape[0], nl.n_unknowns, steps, float(nl.tstep).hex())
+        text += "\n".join(float(v).hex() for v in ph[:, b]) + "\n" + "\n".join(float(v).hex() for v in xdc) + "\n"
+        p = subprocess.run([exe], input=text, capture_output=True, text=True)
+        if p.returncode != 0 and p.returncode < 0:
+            pytest.skip("host cannot run FMA code")
+        assert p.returncode == 0, p.stderr
+        out = p.stdout.split()
+        iters, st, fb, done = int(out[0]), int(out[1]), int(out[2]), int(out[3])
+        x = np.array([float.fromhex(v) for v in out[4:4 + nl.n_unknowns]])
+        per_step = np.array([int(v) for v in out[4 + nl.n_unknowns:4 + nl.n_unknowns + steps]])
+        o = orc.tran(nl.ir_ptr, nl.n_unknowns, ph, b, nl.tstep, nl.tstep * steps, want_rows=False, want_step_iters=True)
+        assert fb == 0 and done == steps, (b, fb, done)
+        assert iters == o["iters"] and np.array_equal(per_step, o["step_iters"]), b
+        assert rel_err(x, o["x_final"]).max() < 1e-9, b
