@@ -285,3 +285,120 @@ def test_generated_fast_transient_kernel_on_the_host_against_the_oracle(codegen,
         assert fb == 0 and done == steps, (b, fb, done)
         assert iters == o["iters"] and np.array_equal(per_step, o["step_iters"]), b
         assert rel_err(x, o["x_final"]).max() < 1e-9, b
+
+
+# ------------------------------------------------------------------ random circuits, no GPU anywhere
+def _sched_line(seq):
+    return ",".join("%d:%d" % (k, p) for k, p in seq) if seq else "-"
+
+
+def _extract(lines, name):
+    at = next((i for i, l in enumerate(lines) if l.startswith(name + "(const double*")), None)
+    if at is None:
+        return None
+    assert lines[at - 1].startswith('extern "C" __global__') and lines[at - 2] == "#pragma clang fp contract(off)"
+    end = next(i for i in range(at, len(lines)) if lines[i] == "#pragma clang fp contract(fast)")
+    return "void\n" + "\n".join(lines[at:end])
+
+
+HOST_MAIN_BOTH = r"""
+int main(int argc, char** argv)
+{
+    // stdin: mode (0 = DC, 1 = transient), P, N, nSteps, dt, P parameters, N start values
+    int mode = 0, P = 0, N = 0, nSteps = 0; double dt = 0.0;
+    if (std::scanf("%d %d %d %d %la", &mode, &P, &N, &nSteps, &dt) != 5) return 2;
+    static double params[4096], x[2048];
+    for (int i = 0; i < P; ++i) if (std::scanf("%la", &params[i]) != 1) return 2;
+    for (int i = 0; i < N; ++i) if (std::scanf("%la", &x[i]) != 1) return 2;
+    unsigned status = 0; unsigned char fallback = 0; int viol[8] = {0};
+    if (mode == 0) {
+#ifdef HAVE_DC
+        int iters = 0;
+        csim_dc_faithful_kernel(params, 1, x, &iters, &status, &fallback, viol, nullptr);
+        std::printf("%d %u %d 0\n", iters, status, (int)fallback);
+#else
+        return 3;
+#endif
+    } else {
+        long long iters = 0; int done = 0;
+        static int stepIters[200000];
+        csim_tran_faithful_kernel(params, 1, dt, 0LL, (long long)nSteps, nullptr, 0, 1, nullptr, x, &iters, &status, stepIters,
+                                  &fallback, &done, viol, nullptr, nullptr, nullptr, nullptr);
+        std::printf("%lld %u %d %d\n", iters, status, (int)fallback, done);
+    }
+    for (int i = 0; i < N; ++i) std::printf("%a\n", x[i]);
+    return 0;
+}
+"""
+
+
+def _call(exe, mode, params, x0, n_steps, dt):
+    text = "%d %d %d %d %s\n" % (mode, len(params), len(x0), n_steps, float(dt).hex())
+    text += "\n".join(float(v).hex() for v in params) + "\n" + "\n".join(float(v).hex() for v in x0) + "\n"
+    p = subprocess.run([exe], input=text, capture_output=True, text=True)
+    assert p.returncode == 0, (p.returncode, p.stderr[-500:])
+    out = p.stdout.split()
+    return int(out[0]), int(out[1]), int(out[2]), int(out[3]), np.array([float.fromhex(v) for v in out[4:4 + len(x0)]])
+
+
+@pytest.mark.parametrize("seed", [11, 23, 31, 47, 7006, 10266, 20010, 20041])
+def test_random_circuit_generated_faithful_kernels_on_the_host(codegen, tmp_path, seed):
+    """Generator fuzz without a GPU: a seeded random circuit (the generator of the GPU fuzzers), pivot sequences recorded
+    by the ORACLE's own LU (operating point and 50 transient steps of instance 0), csim_codegen, g++ -- the faithful DC
+    and transient kernels then reproduce the oracle bit for bit on every instance whose factorisations stay on the
+    recorded sequences (an instance that leaves them reports a hand-over, which is the kernel's contract)."""
+    from circuitsimulator_amd import Netlist
+    from oracle import binding as orc
+    from test_gpu_parity import _random_netlist
+    rs = np.random.RandomState(seed)
+    text = _random_netlist(rs, rs.randint(3, 25), rs.randint(0, 8))
+    nl = Netlist.from_text(text)
+    if not nl.has_nonlinear:
+        pytest.skip("linear circuit: no K1f / K2f (the linear kernels are fuzzed on the GPU, tools/fuzz_linear.py)")
+    path = str(tmp_path / "c.sp")
+    with open(path, "w") as f:
+        f.write(text)
+    N, steps = nl.n_unknowns, 50
+    ph = nl.mc_params_host(seed, 0.05, 0, 4)
+    orc.pivot_log(True)
+    xdc0, _, _ = orc.dc(nl.ir_ptr, N, ph, 0)
+    dc_seqs = orc.pivot_sequences()
+    orc.pivot_log(True)
+    orc.tran(nl.ir_ptr, N, ph, 0, nl.tstep, nl.tstep * steps, want_rows=False)
+    tr_seqs = orc.pivot_sequences()
+    orc.pivot_log(False)
+    # (the transient log includes the operating point the oracle computes first: harmless extra alternatives)
+    sched = "\n".join(_sched_line(q) for q in tr_seqs[:12]) + "\n" + "\n".join("dc " + _sched_line(q) for q in dc_seqs[:12]) + "\n"
+    sfile = str(tmp_path / "c.sched")
+    with open(sfile, "w") as f:
+        f.write(sched)
+    hip = str(tmp_path / "k.hip")
+    p = subprocess.run([codegen, path, sfile, hip], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    lines = open(hip).read().split("\n")
+    tran_body = _extract(lines, "csim_tran_faithful_kernel")
+    dc_body = _extract(lines, "csim_dc_faithful_kernel")
+    assert tran_body is not None
+    cpp = str(tmp_path / "k_host.cpp")
+    with open(cpp, "w") as f:
+        f.write(HOST_PRELUDE + HOST_PRELUDE_TRAN + "#define S(j) Q(%d + (j))\n" % N + ("#define HAVE_DC 1\n" + dc_body if dc_body else "")
+                + "\n" + tran_body + HOST_MAIN_BOTH)
+    exe = str(tmp_path / "k_host")
+    p = subprocess.run(["g++", "-O1", "-ffp-contract=off", "-std=c++17", "-w", cpp, "-o", exe], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    n_dc = n_tr = 0
+    for b in range(4):
+        xo, ito, sto = orc.dc(nl.ir_ptr, N, ph, b)
+        if dc_body:
+            it, st, fb, _, x = _call(exe, 0, ph[:, b], np.zeros(N), 0, 0.0)
+            if not fb:
+                n_dc += 1
+                assert it == ito and st == sto, (seed, b)
+                assert np.array_equal(x, xo), (seed, b, np.abs(x - xo).max())
+        o = orc.tran(nl.ir_ptr, N, ph, b, nl.tstep, nl.tstep * steps, want_rows=False)
+        it, st, fb, done, x = _call(exe, 1, ph[:, b], xo, steps, nl.tstep)
+        if not fb and done == steps and not (st & 0x2 and not o["status"] & 0x2):
+            n_tr += 1
+            assert it == o["iters"] and (st & ~0x100) == o["status"], (seed, b, it, o["iters"], hex(st), hex(o["status"]))
+            assert np.array_equal(x, o["x_final"]), (seed, b, np.abs(x - o["x_final"]).max())
+    assert n_tr >= 1 and (n_dc >= 1 or not dc_body), (n_dc, n_tr)
