@@ -20,7 +20,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--first", type=int, default=100)
     ap.add_argument("--count", type=int, default=100)
+    ap.add_argument("--stress", action="store_true", help="add gate-only and capacitor-only nodes to every circuit")
     a = ap.parse_args()
+    if a.stress:
+        os.environ["CSIM_FUZZ_STRESS"] = "1"
     import pytest
     import test_generated_host as T
     codegen = os.path.join(T.CSRC, "build", "csim_codegen")
