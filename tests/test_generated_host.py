@@ -369,12 +369,13 @@ def test_random_circuit_generated_faithful_kernels_on_the_host(codegen, tmp_path
     with open(path, "w") as f:
         f.write(text)
     N, steps = nl.n_unknowns, 50
+    tstep = nl.tstep * float(os.environ.get("CSIM_FUZZ_TSTEP_SCALE", "1"))      # tools/fuzz_host.py --tstep-scale: hard switching
     ph = nl.mc_params_host(seed, 0.05, 0, 4)
     orc.pivot_log(True)
     xdc0, _, _ = orc.dc(nl.ir_ptr, N, ph, 0)
     dc_seqs = orc.pivot_sequences()
     orc.pivot_log(True)
-    orc.tran(nl.ir_ptr, N, ph, 0, nl.tstep, nl.tstep * steps, want_rows=False)
+    orc.tran(nl.ir_ptr, N, ph, 0, tstep, tstep * steps, want_rows=False)
     tr_seqs = orc.pivot_sequences()
     orc.pivot_log(False)
     # (the transient log includes the operating point the oracle computes first: harmless extra alternatives)
@@ -405,8 +406,8 @@ def test_random_circuit_generated_faithful_kernels_on_the_host(codegen, tmp_path
                 n_dc += 1
                 assert it == ito and st == sto, (seed, b)
                 assert np.array_equal(x, xo), (seed, b, np.abs(x - xo).max())
-        o = orc.tran(nl.ir_ptr, N, ph, b, nl.tstep, nl.tstep * steps, want_rows=False)
-        it, st, fb, done, x = _call(exe, 1, ph[:, b], xo, steps, nl.tstep)
+        o = orc.tran(nl.ir_ptr, N, ph, b, tstep, tstep * steps, want_rows=False)
+        it, st, fb, done, x = _call(exe, 1, ph[:, b], xo, steps, tstep)
         if not fb and done == steps and not (st & 0x2 and not o["status"] & 0x2):
             n_tr += 1
             # (the oracle's transient status carries its operating point's flags; the kernel started from that point)

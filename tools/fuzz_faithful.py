@@ -20,6 +20,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--first", type=int, default=20000)
     ap.add_argument("--count", type=int, default=100)
+    ap.add_argument("--tstep-scale", type=float, default=1.0,
+                    help="multiply the circuits' time step (large steps make the MOSFETs switch hard: several pivot sequences "
+                         "per run, hand-overs to the general kernel and back)")
     ap.add_argument("--stress", action="store_true",
                     help="add degenerate parts to every circuit: a node that is only a MOSFET gate, a node that hangs on "
                          "capacitors only (their matrix rows are gmin alone in DC: the last bit of gmin shows)")
@@ -51,17 +54,18 @@ def main():
         B, steps = 70, 50
         params = eng.mc_params(seed, 0.05, 0, B)
         eng.set_kernel("general")
-        slow = t._run_tran(torch, eng, params, steps, nl.tstep, want_step_iters=True)
+        tstep = nl.tstep * a.tstep_scale
+        slow = t._run_tran(torch, eng, params, steps, tstep, want_step_iters=True)
         eng.set_kernel("auto")
         try:
-            eng.jit_scheduled(params, plan_steps=steps)
+            eng.jit_scheduled(params, tstep=tstep, plan_steps=steps)
             eng.set_kernel("faithful")
         except Exception as e:
             print("seed %d N=%d: no faithful kernel: %s" % (seed, nl.n_unknowns, e), flush=True)
             eng.close()
             continue
         n_run += 1
-        fast = t._run_tran(torch, eng, params, steps, nl.tstep, want_step_iters=True)
+        fast = t._run_tran(torch, eng, params, steps, tstep, want_step_iters=True)
         problems = []
         st = fast["status"]
         kept_dc = (st & 0x80) == 0                       # operating point finished by the generated DC kernel

@@ -21,7 +21,9 @@ def main():
     ap.add_argument("--first", type=int, default=100)
     ap.add_argument("--count", type=int, default=100)
     ap.add_argument("--stress", action="store_true", help="add gate-only and capacitor-only nodes to every circuit")
+    ap.add_argument("--tstep-scale", type=float, default=1.0, help="multiply the circuits' time step (hard switching: several pivot sequences per run)")
     a = ap.parse_args()
+    os.environ["CSIM_FUZZ_TSTEP_SCALE"] = repr(a.tstep_scale)
     if a.stress:
         os.environ["CSIM_FUZZ_STRESS"] = "1"
     import pytest
