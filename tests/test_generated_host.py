@@ -414,3 +414,72 @@ def test_random_circuit_generated_faithful_kernels_on_the_host(codegen, tmp_path
             assert it == o["iters"] and ((st & ~0x100) | sto) == o["status"], (seed, b, it, o["iters"], hex(st), hex(o["status"]))
             assert np.array_equal(x, o["x_final"]), (seed, b, np.abs(x - o["x_final"]).max())
     assert n_tr >= 1 and (n_dc >= 1 or not dc_body), (n_dc, n_tr)
+
+
+@pytest.mark.parametrize("seed", [11, 47, 7006])
+def test_random_circuit_generated_fast_kernel_on_the_host(codegen, tmp_path, seed):
+    """The same, for the FAST lane-per-instance transient kernel (reciprocal pivots, contraction, slow-step rule,
+    near-threshold guard), compiled with FMA contraction on: per-step NR totals equal to the oracle's and states within
+    the 1e-9 bar on every instance the kernel keeps (a step it hands over -- unrecorded pivots, a slow step, a guarded
+    decision -- ends the comparison for that instance: the hand-over targets are GPU kernels)."""
+    from circuitsimulator_amd import Netlist
+    from oracle import binding as orc
+    from conftest import rel_err
+    from test_gpu_parity import _random_netlist
+    rs = np.random.RandomState(seed)
+    text = _random_netlist(rs, rs.randint(3, 25), rs.randint(0, 8))
+    nl = Netlist.from_text(text)
+    if not nl.has_nonlinear:
+        pytest.skip("linear circuit")
+    path = str(tmp_path / "c.sp")
+    with open(path, "w") as f:
+        f.write(text)
+    N, steps = nl.n_unknowns, 50
+    tstep = nl.tstep * float(os.environ.get("CSIM_FUZZ_TSTEP_SCALE", "1"))
+    ph = nl.mc_params_host(seed, 0.05, 0, 4)
+    orc.pivot_log(True)
+    orc.tran(nl.ir_ptr, N, ph, 0, tstep, tstep * steps, want_rows=False)
+    tr_seqs = orc.pivot_sequences()
+    orc.pivot_log(False)
+    sfile = str(tmp_path / "c.sched")
+    with open(sfile, "w") as f:
+        f.write("\n".join(_sched_line(q) for q in tr_seqs[:12]) + "\n")
+    hip = str(tmp_path / "k.hip")
+    p = subprocess.run([codegen, path, sfile, hip], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    lines = open(hip).read().split("\n")
+    at = next(i for i, l in enumerate(lines) if l.startswith("csim_tran_sched_kernel(const double*"))
+    end = next(i for i in range(at + 1, len(lines)) if lines[i].startswith('extern "C" __global__') or lines[i].startswith("#pragma clang fp"))
+    body = "void\n" + "\n".join(lines[at:end])
+    main = HOST_MAIN_TRAN.replace("csim_tran_faithful_kernel", "csim_tran_sched_kernel").replace(
+        "viol, nullptr, nullptr, nullptr, nullptr);", "viol, nearX, &nearStep, &nearIt, &nearItAfter);").replace(
+        "static int stepIters[200000];", "static int stepIters[200000]; static double nearX[2048]; int nearStep = 0, nearIt = 0; long long nearItAfter = 0;")
+    rcp = ("static inline double __builtin_amdgcn_rcp(double a) { return 1.0 / a; }\nusing std::fma;\n"
+           "static inline double rcp_nr(double a) { const double r = __builtin_amdgcn_rcp(a); const double e = fma(-a, r, 1.0); return fma(fma(e, e, e), r, r); }\n")
+    cpp = str(tmp_path / "s_host.cpp")
+    with open(cpp, "w") as f:
+        f.write(HOST_PRELUDE + HOST_PRELUDE_TRAN + "#define S(j) Q(%d + (j))\n" % N + rcp + body + main)
+    exe = str(tmp_path / "s_host")
+    p = subprocess.run(["g++", "-O1", "-ffp-contract=fast", "-mfma", "-std=c++17", "-w", cpp, "-o", exe], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    kept = 0
+    for b in range(4):
+        xo, _, sto = orc.dc(nl.ir_ptr, N, ph, b)
+        o = orc.tran(nl.ir_ptr, N, ph, b, tstep, tstep * steps, want_rows=False, want_step_iters=True)
+        text_in = "%d %d %d %s\n" % (ph.shape[0], N, steps, float(tstep).hex())
+        text_in += "\n".join(float(v).hex() for v in ph[:, b]) + "\n" + "\n".join(float(v).hex() for v in xo) + "\n"
+        p = subprocess.run([exe], input=text_in, capture_output=True, text=True)
+        if p.returncode < 0:
+            pytest.skip("host cannot run FMA code")
+        assert p.returncode == 0, p.stderr
+        out = p.stdout.split()
+        iters, st, fb, done = int(out[0]), int(out[1]), int(out[2]), int(out[3])
+        x = np.array([float.fromhex(v) for v in out[4:4 + N]])
+        per_step = np.array([int(v) for v in out[4 + N:4 + N + steps]])
+        # the steps the kernel completed itself must carry the oracle's pass counts, whatever happened afterwards
+        assert np.array_equal(per_step[:done], o["step_iters"][:done]), (seed, b, done)
+        if fb == 0 and done == steps:
+            kept += 1
+            assert iters == o["iters"], (seed, b)
+            assert rel_err(x, o["x_final"]).max() < 1e-9, (seed, b, rel_err(x, o["x_final"]).max())
+    print("seed %d: %d of 4 instances kept by the fast kernel" % (seed, kept))
