@@ -288,6 +288,24 @@ def test_generated_fast_transient_kernel_on_the_host_against_the_oracle(codegen,
 
 
 # ------------------------------------------------------------------ random circuits, no GPU anywhere
+def _fuzz_netlist(rs):
+    """The random circuit of the GPU fuzzers; with CSIM_FUZZ_STRESS=1 (tools/fuzz_host.py --stress) plus a node that is only
+    a MOSFET gate, one that is a gate and a capacitor, and one that hangs on capacitors only."""
+    from test_gpu_parity import _random_netlist
+    text = _random_netlist(rs, rs.randint(3, 25), rs.randint(0, 8))
+    if os.environ.get("CSIM_FUZZ_STRESS") == "1":
+        nodes = sorted({w for ln in text.splitlines() if ln[:1] in "RCL" for w in ln.split()[1:3] if w.startswith("n")})
+        if len(nodes) >= 2:
+            d_, s_ = rs.choice(nodes, 2, replace=False)
+            extra = ["MG1 %s gx1 %s n %.3ge-6 0.35e-6 2" % (d_, s_, rs.uniform(5, 40)),
+                     "MG2 %s gx2 vdd p %.3ge-6 0.35e-6 1" % (rs.choice(nodes), rs.uniform(5, 40)),
+                     "CG2 gx2 %s %.4g" % (rs.choice(nodes), 10 ** rs.uniform(-14, -12)),
+                     "CX1 cx1 0 %.4g" % 10 ** rs.uniform(-14, -12),
+                     "CX2 cx1 %s %.4g" % (rs.choice(nodes), 10 ** rs.uniform(-14, -12))]
+            text = text.replace(".MODEL 1", "\n".join(extra) + "\n.MODEL 1", 1)
+    return text
+
+
 def _sched_line(seq):
     return ",".join("%d:%d" % (k, p) for k, p in seq) if seq else "-"
 
@@ -351,17 +369,7 @@ def test_random_circuit_generated_faithful_kernels_on_the_host(codegen, tmp_path
     from oracle import binding as orc
     from test_gpu_parity import _random_netlist
     rs = np.random.RandomState(seed)
-    text = _random_netlist(rs, rs.randint(3, 25), rs.randint(0, 8))
-    if os.environ.get("CSIM_FUZZ_STRESS") == "1":          # tools/fuzz_host.py --stress: gate-only and capacitor-only nodes
-        nodes = sorted({w for ln in text.splitlines() if ln[:1] in "RCL" for w in ln.split()[1:3] if w.startswith("n")})
-        if len(nodes) >= 2:
-            d_, s_ = rs.choice(nodes, 2, replace=False)
-            extra = ["MG1 %s gx1 %s n %.3ge-6 0.35e-6 2" % (d_, s_, rs.uniform(5, 40)),
-                     "MG2 %s gx2 vdd p %.3ge-6 0.35e-6 1" % (rs.choice(nodes), rs.uniform(5, 40)),
-                     "CG2 gx2 %s %.4g" % (rs.choice(nodes), 10 ** rs.uniform(-14, -12)),
-                     "CX1 cx1 0 %.4g" % 10 ** rs.uniform(-14, -12),
-                     "CX2 cx1 %s %.4g" % (rs.choice(nodes), 10 ** rs.uniform(-14, -12))]
-            text = text.replace(".MODEL 1", "\n".join(extra) + "\n.MODEL 1", 1)
+    text = _fuzz_netlist(rs)
     nl = Netlist.from_text(text)
     if not nl.has_nonlinear:
         pytest.skip("linear circuit: no K1f / K2f (the linear kernels are fuzzed on the GPU, tools/fuzz_linear.py)")
@@ -427,7 +435,7 @@ def test_random_circuit_generated_fast_kernel_on_the_host(codegen, tmp_path, see
     from conftest import rel_err
     from test_gpu_parity import _random_netlist
     rs = np.random.RandomState(seed)
-    text = _random_netlist(rs, rs.randint(3, 25), rs.randint(0, 8))
+    text = _fuzz_netlist(rs)
     nl = Netlist.from_text(text)
     if not nl.has_nonlinear:
         pytest.skip("linear circuit")
