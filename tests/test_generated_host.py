@@ -365,18 +365,26 @@ def test_random_circuit_generated_faithful_kernels_on_the_host(codegen, tmp_path
     by the ORACLE's own LU (operating point and 50 transient steps of instance 0), csim_codegen, g++ -- the faithful DC
     and transient kernels then reproduce the oracle bit for bit on every instance whose factorisations stay on the
     recorded sequences (an instance that leaves them reports a hand-over, which is the kernel's contract)."""
+    rs = np.random.RandomState(seed)
+    _check_faithful_on_host(codegen, tmp_path, _fuzz_netlist(rs), seed)
+
+
+def test_pulse_and_pwl_sources_generated_faithful_kernels_on_the_host(codegen, tmp_path):
+    """tests/golden/pulse_pwl.sp: TranWaveform::eval PULSE / PWL (reference include/sim.hpp:80-138) on voltage and current
+    sources, through the generated faithful kernels on the host: bit for bit the oracle."""
+    _check_faithful_on_host(codegen, tmp_path, open(netlist_path("pulse_pwl.sp")).read(), 99, steps=400)
+
+
+def _check_faithful_on_host(codegen, tmp_path, text, seed, steps=50):
     from circuitsimulator_amd import Netlist
     from oracle import binding as orc
-    from test_gpu_parity import _random_netlist
-    rs = np.random.RandomState(seed)
-    text = _fuzz_netlist(rs)
     nl = Netlist.from_text(text)
     if not nl.has_nonlinear:
         pytest.skip("linear circuit: no K1f / K2f (the linear kernels are fuzzed on the GPU, tools/fuzz_linear.py)")
     path = str(tmp_path / "c.sp")
     with open(path, "w") as f:
         f.write(text)
-    N, steps = nl.n_unknowns, 50
+    N = nl.n_unknowns
     tstep = nl.tstep * float(os.environ.get("CSIM_FUZZ_TSTEP_SCALE", "1"))      # tools/fuzz_host.py --tstep-scale: hard switching
     ph = nl.mc_params_host(seed, 0.05, 0, 4)
     orc.pivot_log(True)
